@@ -1,0 +1,290 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+A CPU (torch fp32) restatement of the arithmetic of the reference's ``OCRModel.generate()``
+hot path, written from the behaviour of the cited reference lines.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module,
+and there only as the checker / the timed CPU baseline.  ``texocr_amd`` never imports it.
+
+Parity status: PINNED.  The reference has no tests or golden vectors for this path
+(SURVEY.md section 4), so this restatement is pinned against outputs of the reference
+itself, produced in the build container by ``oracle/capture_golden.py`` (which imports
+``/root/reference``) and committed as fixtures under ``tests/golden/``.
+``tests/test_oracle_golden.py`` checks every function here against those fixtures.
+
+Third-party arithmetic the reference relies on (un-vendored, unpinned in its
+requirements.txt): torch ATen CPU kernels -- ``F.layer_norm`` (eps 1e-5, biased variance),
+``F.gelu`` (exact erf), ``F.softmax`` (fp32), ``nn.GLU`` (a * sigmoid(b)), ``nn.Conv2d`` --
+and einops reshapes.  Captured with torch 2.10.0, einops 0.8.2.
+
+All tensors fp32, token ids int64.  ``sd`` is a reference-layout state dict of torch
+tensors (see ``texocr_amd.synth.state_dict_layout``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+DIM_HEAD = 64           # reference model/attention.py:76
+SCALE = DIM_HEAD ** -0.5  # attention.py:80 (0.125 exactly)
+SD = Dict[str, torch.Tensor]
+
+
+def to_torch_sd(sd_np) -> SD:
+    return {k: torch.from_numpy(v) if not isinstance(v, torch.Tensor) else v for k, v in sd_np.items()}
+
+
+# --------------------------------------------------------------------------------------
+# blocks
+# --------------------------------------------------------------------------------------
+def layer_norm(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """nn.LayerNorm(D): eps 1e-5, affine, biased variance (attention.py:200, encoder.py:121,
+    decoder.py:30)."""
+    return F.layer_norm(x, (x.shape[-1],), g, b, 1e-5)
+
+
+def _split_heads(t: torch.Tensor) -> torch.Tensor:
+    # 'b n (h d) -> b h n d' (attention.py:127): feature f = head*64 + d
+    B, n, inner = t.shape
+    return t.view(B, n, inner // DIM_HEAD, DIM_HEAD).permute(0, 2, 1, 3)
+
+
+def mha(sd: SD, p: str, xq: torch.Tensor, src: torch.Tensor, causal: bool,
+        kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """MultiHeadAttention.forward with all-True padding masks (attention.py:101-180).
+
+    ``xq`` (B,nq,D) queries' input, ``src`` (B,nk,D) keys'/values' input (== xq for self
+    attention, the raw encoder output for cross attention, attention.py:113-126).  If ``kv``
+    is given it is the already projected, head-split (k, v) -- used by the cached decoder.
+    Causal fill: S[i, j] = -FLT_MAX for j > i + (nk - nq) (attention.py:158-163; the
+    ``F.pad(mask, (j-i, 0))`` makes it correct for nq < nk)."""
+    q = _split_heads(xq @ sd[f"{p}.q.weight"].t())                         # :124,127 (no bias :89)
+    if kv is None:
+        k = _split_heads(src @ sd[f"{p}.k.weight"].t())                    # :125
+        v = _split_heads(src @ sd[f"{p}.v.weight"].t())                    # :126
+    else:
+        k, v = kv
+    energy = torch.matmul(q, k.transpose(-1, -2)) * SCALE                  # :148
+    if causal:
+        nq, nk = energy.shape[-2:]
+        i = torch.arange(nq).view(nq, 1)
+        j = torch.arange(nk).view(1, nk)
+        energy = energy.masked_fill(j > i + (nk - nq), -torch.finfo(energy.dtype).max)  # :149,163
+    attn = F.softmax(energy, dim=-1)                                       # :166
+    out = torch.matmul(attn, v)                                            # :172
+    B, H, nq, dh = out.shape
+    out = out.permute(0, 2, 1, 3).reshape(B, nq, H * dh)                   # :173
+    y = out @ sd[f"{p}.fc_out.0.weight"].t() + sd[f"{p}.fc_out.0.bias"]    # :96-97
+    a, g = y.chunk(2, dim=-1)                                              # nn.GLU :98
+    return a * torch.sigmoid(g)
+
+
+def project_kv(sd: SD, p: str, src: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return (_split_heads(src @ sd[f"{p}.k.weight"].t()), _split_heads(src @ sd[f"{p}.v.weight"].t()))
+
+
+def ffn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
+    """MLP with GeGLU (attention.py:9-17, 41-67): value = first half, gelu gate = second half."""
+    u = x @ sd[f"{p}.fc_in.fc.weight"].t() + sd[f"{p}.fc_in.fc.bias"]
+    a, g = u.chunk(2, dim=-1)
+    return (a * F.gelu(g)) @ sd[f"{p}.fc_out.weight"].t() + sd[f"{p}.fc_out.bias"]
+
+
+def stack(sd: SD, prefix: str, kinds: List[str], x: torch.Tensor, enc: Optional[torch.Tensor],
+          causal: bool, trace: Optional[list] = None) -> torch.Tensor:
+    """AttentionLayers.forward (attention.py:223-269): ONE shared LayerNorm (:200,221), applied
+    before every block and again after every residual add except the last (:242-259)."""
+    g, b = sd[f"{prefix}.layers.0.0.weight"], sd[f"{prefix}.layers.0.0.bias"]
+    last = len(kinds) - 1
+    for s, kind in enumerate(kinds):
+        p = f"{prefix}.layers.{s}.1"
+        r = x
+        z = layer_norm(x, g, b)
+        if kind == "self":
+            o = mha(sd, p, z, z, causal)
+        elif kind == "cross":
+            o = mha(sd, p, z, enc, False)
+        else:
+            o = ffn(sd, p, z)
+        x = o + r
+        if s != last:
+            x = layer_norm(x, g, b)
+        if trace is not None:
+            trace.append(x)
+    return x
+
+
+def kinds_of(sd: SD, prefix: str) -> List[str]:
+    kinds, s = [], 0
+    while f"{prefix}.layers.{s}.0.weight" in sd:
+        p = f"{prefix}.layers.{s}.1"
+        if f"{p}.fc_in.fc.weight" in sd:
+            kinds.append("mlp")
+        elif prefix.startswith("decoder") and s % 3 == 1:
+            kinds.append("cross")
+        else:
+            kinds.append("self")
+        s += 1
+    return kinds
+
+
+# --------------------------------------------------------------------------------------
+# encoder
+# --------------------------------------------------------------------------------------
+def pos_ids(h: int, w: int, canvas_grid: int) -> torch.Tensor:
+    """[0] ++ (r * max_w + c + 1) over the MAX-canvas grid (encoder.py:136-141)."""
+    r = torch.arange(h).view(h, 1)
+    c = torch.arange(w).view(1, w)
+    return torch.cat([torch.zeros(1, dtype=torch.long), (r * canvas_grid + c + 1).reshape(-1)])
+
+
+def patch_embed(sd: SD, img: torch.Tensor) -> torch.Tensor:
+    """Conv2d(C, D, k=16, s=16)+bias, flatten(2).transpose(1,2) (encoder.py:22,25-28)."""
+    w = sd["encoder.patch_embed.proj.weight"]
+    x = F.conv2d(img, w, sd["encoder.patch_embed.proj.bias"], stride=w.shape[-1])
+    return x.flatten(2).transpose(1, 2)
+
+
+def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None) -> torch.Tensor:
+    """VisionTransformer.forward (encoder.py:128-152), head = Identity."""
+    B, C, H, W = img.shape
+    P = sd["encoder.patch_embed.proj.weight"].shape[-1]
+    grid = int(round(math.sqrt(sd["encoder.pos_embed"].shape[1] - 1)))
+    x = patch_embed(sd, img)
+    x = torch.cat([sd["encoder.cls_token"].expand(B, -1, -1), x], dim=1)    # :133-134
+    x = x + sd["encoder.pos_embed"][:, pos_ids(H // P, W // P, grid)]       # :143
+    x = stack(sd, "encoder.attn_layers", kinds_of(sd, "encoder.attn_layers"), x, None, False, trace)
+    return layer_norm(x, sd["encoder.norm.weight"], sd["encoder.norm.bias"])  # :148
+
+
+# --------------------------------------------------------------------------------------
+# decoder
+# --------------------------------------------------------------------------------------
+def decoder_net(sd: SD, tokens: torch.Tensor, enc: torch.Tensor, trace: Optional[list] = None) -> torch.Tensor:
+    """Transformer.forward with an all-True mask (decoder.py:41-67): logits for ALL positions."""
+    T = tokens.shape[1]
+    x = sd["decoder.net.token_embedding.weight"][tokens]                    # :51
+    x = x + sd["decoder.net.pos_embedding.embedding.weight"][:T][None]      # :52, attention.py:30-32
+    x = stack(sd, "decoder.net.attn_layers", kinds_of(sd, "decoder.net.attn_layers"), x, enc, True, trace)
+    x = layer_norm(x, sd["decoder.net.norm.weight"], sd["decoder.net.norm.bias"])   # :57
+    return x @ sd["decoder.net.to_logits.weight"].t() + sd["decoder.net.to_logits.bias"]  # :60
+
+
+def topk_filter(logits: torch.Tensor, threshold: float = 0.9) -> torch.Tensor:
+    """utils.topk (utils.py:85-91): keep k = int((1-threshold)*V) largest, others -inf."""
+    k = int((1 - threshold) * logits.shape[-1])
+    val, ind = torch.topk(logits, k)
+    out = torch.full_like(logits, float("-inf"))
+    out.scatter_(1, ind, val)
+    return out
+
+
+def _all_rows_have_eos(output: torch.Tensor, eos: Optional[int]) -> bool:
+    # decoder.py:115-116 -- a GLOBAL break: every row must contain eos somewhere (BOS column included)
+    return eos is not None and bool((output == eos).any(dim=1).all())
+
+
+@torch.no_grad()
+def generate_recompute(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
+                       net_max_len: Optional[int] = None, collect_logits: bool = False):
+    """The reference algorithm as written: full-prefix recompute each step, cross K/V
+    re-projected each step, sliding window (ocr_model.py:46-66, decoder.py:77-122), with the
+    sampler replaced by argmax (greedy; argmax survives top-k and softmax(/temp))."""
+    enc = encode(sd, img)
+    B = img.shape[0]
+    net_max_len = net_max_len or sd["decoder.net.pos_embedding.embedding.weight"].shape[0]
+    output = torch.full((B, 1), bos, dtype=torch.long)                      # ocr_model.py:57
+    steps = []
+    for _ in range(max_len):                                                # decoder.py:97
+        x = output[:, -net_max_len:]                                        # :99
+        logits = decoder_net(sd, x, enc)[:, -1, :]                          # :103
+        if collect_logits:
+            steps.append(logits)
+        nxt = logits.argmax(dim=-1, keepdim=True)
+        output = torch.cat([output, nxt], dim=-1)                           # :111
+        if _all_rows_have_eos(output, eos):                                 # :115
+            break
+    toks = output[:, 1:]                                                    # :118
+    return (toks, torch.stack(steps, 1)) if collect_logits else toks
+
+
+class CachedDecoder:
+    """KV-cached form of the same arithmetic: per step only the new position is
+    pushed through the stack; self-attention K/V of the *normed* sub-layer input are cached,
+    cross-attention K/V are projected once from the raw encoder output.  Valid while the
+    prefix length stays <= the positional table (no sliding window, decoder.py:99-100)."""
+
+    def __init__(self, sd: SD, enc: torch.Tensor):
+        self.sd, self.enc = sd, enc
+        self.prefix = "decoder.net.attn_layers"
+        self.kinds = kinds_of(sd, self.prefix)
+        self.cross = {s: project_kv(sd, f"{self.prefix}.layers.{s}.1", enc)
+                      for s, k in enumerate(self.kinds) if k == "cross"}
+        self.self_kv: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.t = 0
+
+    def step(self, tok: torch.Tensor) -> torch.Tensor:
+        """tok (B,) int64 = token at position self.t; returns logits (B, V) for position self.t."""
+        sd = self.sd
+        if self.t >= sd["decoder.net.pos_embedding.embedding.weight"].shape[0]:
+            raise ValueError("prefix longer than the positional table: the reference would slide its window")
+        x = (sd["decoder.net.token_embedding.weight"][tok] +
+             sd["decoder.net.pos_embedding.embedding.weight"][self.t])[:, None, :]
+        g, b = sd[f"{self.prefix}.layers.0.0.weight"], sd[f"{self.prefix}.layers.0.0.bias"]
+        last = len(self.kinds) - 1
+        for s, kind in enumerate(self.kinds):
+            p = f"{self.prefix}.layers.{s}.1"
+            r = x
+            z = layer_norm(x, g, b)
+            if kind == "self":
+                k1, v1 = project_kv(sd, p, z)
+                if s in self.self_kv:
+                    k0, v0 = self.self_kv[s]
+                    k1, v1 = torch.cat([k0, k1], 2), torch.cat([v0, v1], 2)
+                self.self_kv[s] = (k1, v1)
+                o = mha(sd, p, z, z, True, kv=(k1, v1))
+            elif kind == "cross":
+                o = mha(sd, p, z, self.enc, False, kv=self.cross[s])
+            else:
+                o = ffn(sd, p, z)
+            x = o + r
+            if s != last:
+                x = layer_norm(x, g, b)
+        x = layer_norm(x, sd["decoder.net.norm.weight"], sd["decoder.net.norm.bias"])
+        self.t += 1
+        return (x @ sd["decoder.net.to_logits.weight"].t() + sd["decoder.net.to_logits.bias"])[:, 0, :]
+
+
+@torch.no_grad()
+def generate_cached(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
+                    collect_logits: bool = False, enc: Optional[torch.Tensor] = None):
+    enc = encode(sd, img) if enc is None else enc
+    B = enc.shape[0]
+    dec = CachedDecoder(sd, enc)
+    tok = torch.full((B,), bos, dtype=torch.long)
+    output = tok[:, None]
+    steps = []
+    for _ in range(max_len):
+        logits = dec.step(tok)
+        if collect_logits:
+            steps.append(logits)
+        tok = logits.argmax(dim=-1)
+        output = torch.cat([output, tok[:, None]], dim=-1)
+        if _all_rows_have_eos(output, eos):
+            break
+    toks = output[:, 1:]
+    return (toks, torch.stack(steps, 1)) if collect_logits else toks
+
+
+@torch.no_grad()
+def teacher_forced_logits_cached(sd: SD, enc: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+    """Cached-form equivalent of decoder_net(): logits (B, T, V) for a given prefix."""
+    dec = CachedDecoder(sd, enc)
+    return torch.stack([dec.step(tokens[:, t]) for t in range(tokens.shape[1])], 1)
+
+
+def sample_probs(logits: torch.Tensor, temp: float) -> torch.Tensor:
+    """The reference's sampling distribution for one step (decoder.py:104-107)."""
+    return F.softmax(topk_filter(logits) / temp, dim=-1)

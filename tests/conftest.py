@@ -1,0 +1,27 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLD, f"{name}.json")) as f:
+        meta = json.load(f)
+    arrays = dict(np.load(os.path.join(GOLD, f"{name}.npz")))
+    return meta, arrays
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden

@@ -1,0 +1,143 @@
+"""The CPU oracle (oracle/cpu_ref.py) against golden vectors captured from the reference
+(oracle/capture_golden.py).  This is what pins the oracle; the GPU parity tests then compare
+the HIP path with the oracle and with the same fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from texocr_amd import synth
+from texocr_amd.config import Dims
+from conftest import load_golden
+
+
+def model_of(meta):
+    d = Dims(**meta["dims"])
+    sd = cpu_ref.to_torch_sd(synth.synth_state_dict(d, meta["weight_seed"]))
+    img = torch.from_numpy(synth.synth_images(*meta["image_shape"], seed=meta["image_seed"]))
+    return d, sd, img
+
+
+def first_divergence(a, b):
+    """index of the first step where token rows differ (per row), or T."""
+    neq = (a != b)
+    T = a.shape[1]
+    return np.where(neq.any(1), neq.argmax(1), T)
+
+
+def test_state_dict_layout_matches_reference():
+    meta, _ = load_golden("tiny")
+    d = Dims(**meta["dims"])
+    ours = [[k, list(s), c] for k, s, c in synth.state_dict_layout(d)]
+    assert ours == meta["state_dict_layout"]
+    sd = synth.synth_state_dict(d, 7)
+    # aliased shared-LN keys are one array
+    assert sd["encoder.attn_layers.layers.3.0.weight"] is sd["encoder.attn_layers.layers.0.0.weight"]
+    assert sd["decoder.net.attn_layers.layers.5.0.bias"] is sd["decoder.net.attn_layers.layers.0.0.bias"]
+
+
+def test_tiny_every_stage():
+    meta, g = load_golden("tiny")
+    d, sd, img = model_of(meta)
+    np.testing.assert_allclose(cpu_ref.patch_embed(sd, img).numpy(), g["patch_embed"], atol=2e-6)
+    trace = []
+    enc = cpu_ref.encode(sd, img, trace)
+    np.testing.assert_allclose(enc.numpy(), g["enc"], atol=5e-6)
+    # hiddens: x entering each layer's self sub-layer = after the previous layer's mlp sub-layer
+    # (sub-layer trace index 2*i-1), last = stack output
+    for i in range(1, d.enc_layers):
+        np.testing.assert_allclose(trace[2 * i - 1].numpy(), g["enc_hiddens"][i], atol=5e-6)
+    np.testing.assert_allclose(trace[-1].numpy(), g["enc_hiddens"][-1], atol=5e-6)
+    toks = torch.from_numpy(g["tokens"].astype(np.int64))
+    prefix = torch.cat([torch.full((2, 1), d.bos, dtype=torch.long), toks[:, :-1]], 1)
+    dtrace = []
+    tfl = cpu_ref.decoder_net(sd, prefix, enc, dtrace)
+    np.testing.assert_allclose(tfl.numpy(), g["tf_logits"], atol=1e-5)
+    for i in range(1, d.dec_layers):
+        np.testing.assert_allclose(dtrace[3 * i - 1].numpy(), g["dec_hiddens"][i], atol=1e-5)
+    np.testing.assert_allclose(dtrace[-1].numpy(), g["dec_hiddens"][-1], atol=1e-5)
+    # cached form == recompute form
+    tfc = cpu_ref.teacher_forced_logits_cached(sd, enc, prefix)
+    np.testing.assert_allclose(tfc.numpy(), g["tf_logits"], atol=1e-5)
+    t_re, l_re = cpu_ref.generate_recompute(sd, img, d.bos, d.eos, meta["max_len"], collect_logits=True)
+    t_ca, l_ca = cpu_ref.generate_cached(sd, img, d.bos, d.eos, meta["max_len"], collect_logits=True)
+    assert np.array_equal(t_re.numpy(), g["tokens"])
+    assert np.array_equal(t_ca.numpy(), g["tokens"])
+    np.testing.assert_allclose(l_re.numpy(), g["step_logits"], atol=1e-5)
+    np.testing.assert_allclose(l_ca.numpy(), g["step_logits"], atol=1e-5)
+
+
+def test_cfg1_greedy_tokens_and_logits():
+    meta, g = load_golden("cfg1_b4_224x224")
+    d, sd, img = model_of(meta)
+    enc = cpu_ref.encode(sd, img)
+    np.testing.assert_allclose(enc[0].numpy(), g["enc0"], atol=2e-5)
+    np.testing.assert_allclose(enc.double().sum((1, 2)).numpy(), g["enc_sum"], rtol=0, atol=2e-2)
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, 256, collect_logits=True, enc=enc)
+    assert toks.shape == (4, 256)          # eos never fires for all rows -> full length
+    assert np.array_equal(toks.numpy(), g["tokens"]), first_divergence(toks.numpy(), g["tokens"])
+    assert float(g["margin"].min()) > 5e-5
+    np.testing.assert_allclose(logits[:2, :16].numpy(), g["logits_first16"], atol=2e-5)
+    np.testing.assert_allclose(logits[:2, -4:].numpy(), g["logits_last4"], atol=5e-5)
+    v = torch.gather(logits, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    np.testing.assert_allclose(v.numpy(), g["top5_vals"], atol=5e-5)
+
+
+def test_cfg2_shape_encoder_and_decode():
+    meta, g = load_golden("cfg2_b2_224x672")
+    d, sd, img = model_of(meta)
+    enc = cpu_ref.encode(sd, img)
+    assert enc.shape == (2, 589, 256)
+    np.testing.assert_allclose(enc[:, ::8].numpy(), g["enc_rows"], atol=2e-5)
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, 48, collect_logits=True, enc=enc)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    np.testing.assert_allclose(logits[:, :8].numpy(), g["logits_first8"], atol=2e-5)
+
+
+def test_recompute_mode_matches_reference_cfg1_prefix():
+    """The 'reference CPU path' baseline mode (no cache) on the first 12 steps of config 1."""
+    meta, g = load_golden("cfg1_b4_224x224")
+    d, sd, img = model_of(meta)
+    toks = cpu_ref.generate_recompute(sd, img[:2], d.bos, d.eos, 12)
+    assert np.array_equal(toks.numpy(), g["tokens"][:2, :12])
+
+
+def test_pos_ids():
+    meta, g = load_golden("posids")
+    for H, W, canvas in meta["cases"]:
+        ids = cpu_ref.pos_ids(H // 16, W // 16, canvas // 16).numpy()
+        assert np.array_equal(ids, g[f"ids_{H}_{W}_{canvas}"])
+    lc = meta["live_case"]
+    d, sd, img = model_of(lc)
+    np.testing.assert_allclose(cpu_ref.encode(sd, img).numpy(), g["enc_32_80_96"], atol=5e-6)
+
+
+def test_eos_global_break():
+    meta, g = load_golden("eos_break")
+    d, sd, img = model_of(meta)
+    for case in meta["cases"]:
+        for gen in (cpu_ref.generate_cached, cpu_ref.generate_recompute):
+            t = gen(sd, img, d.bos, case["eos"], meta["max_len"])
+            assert t.shape[1] == case["n_steps"], case
+            assert np.array_equal(t.numpy(), g[f"tokens_{case['name']}"])
+    names = {c["name"]: c for c in meta["cases"]}
+    assert names["both"]["n_steps"] < meta["max_len"]       # early global break
+    assert names["only_row0"]["n_steps"] == meta["max_len"]  # a finished row keeps generating
+    assert names["eos_is_bos"]["n_steps"] == 1
+
+
+def test_sliding_window_recompute_only():
+    meta, g = load_golden("sliding_window")
+    d, sd, img = model_of(meta)
+    t = cpu_ref.generate_recompute(sd, img, d.bos, d.eos, meta["max_len"])
+    assert np.array_equal(t.numpy(), g["tokens"])
+    with pytest.raises(ValueError):
+        cpu_ref.generate_cached(sd, img, d.bos, d.eos, meta["max_len"])
+
+
+def test_sampling_distribution():
+    meta, g = load_golden("sampling")
+    logits = torch.from_numpy(g["logits"])
+    filt = cpu_ref.topk_filter(logits)
+    assert int((filt[0] > -float("inf")).sum()) == meta["support"] == 99
+    np.testing.assert_allclose(cpu_ref.sample_probs(logits, meta["temp"]).numpy(), g["probs"], atol=1e-7)
