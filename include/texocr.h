@@ -1,0 +1,108 @@
+/*
+ * texocr.h -- C ABI of the MI355X-native engine for TeXOCR's OCRModel.generate() hot path.
+ *
+ * The reference (olibridge01/TeXOCR) is pure Python; it has no FFI/plugin interface, so the drop-in
+ * boundary is its nn.Module call surface.  Each entry point below replaces one reference callable
+ * (file:line relative to the reference tree); texocr_amd/model.py binds them through ctypes and presents
+ * the reference's own class/method names.  Plain pointers and sizes only -- no torch types.
+ *
+ * Conventions
+ *   - every *_dev pointer is DEVICE memory owned by the caller; the engine owns its weight copy, KV caches
+ *     and workspace (allocated in txo_engine_create, freed in txo_engine_destroy; no allocation in any
+ *     encode/decode call);
+ *   - all work is enqueued on the caller's hipStream_t (`stream`, may be NULL = default stream) and is
+ *     asynchronous except where noted; one engine per (device, stream); a handle is not thread-safe;
+ *   - return value: 0 = ok, <0 = error (TXO_E_*); txo_last_error() returns a thread-local message;
+ *   - images: float32 NCHW; token ids: int64; encoder output / logits: float32.
+ */
+#ifndef TEXOCR_H
+#define TEXOCR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TXO_OK 0
+#define TXO_E_INVALID (-1)   /* bad argument / unsupported shape (maps to ValueError)  */
+#define TXO_E_STATE (-2)     /* call order / missing weights (maps to RuntimeError)    */
+#define TXO_E_HIP (-3)       /* HIP runtime error (maps to RuntimeError)               */
+
+#define TXO_F32 0            /* parity mode: f32 storage, exact-f32 MFMA               */
+#define TXO_BF16 1           /* perf mode: bf16 weights / K,V caches / GEMM operands, f32 accumulate */
+
+typedef struct txo_engine txo_engine;
+
+/* Mirrors the values create_model(config) reads (model/ocr_model.py:113-130, model/encoder.py:172-191,
+ * model/decoder.py:148-173) plus capacity limits for the engine-owned buffers. */
+typedef struct txo_config {
+    int32_t canvas;        /* VisionTransformer img_size (square max canvas, pixels), encoder.py:95      */
+    int32_t in_channels;   /* PatchEmbedding in_channels, encoder.py:13                                   */
+    int32_t embed_dim;     /* encoder == decoder width (no enc->dec projection, attention.py:89-91)       */
+    int32_t enc_heads, enc_layers, dec_heads, dec_layers;
+    int32_t enc_exp, dec_exp;   /* FFN expansion (MLP exp_factor, attention.py:46)                        */
+    int32_t vocab;         /* config['vocab_size']                                                        */
+    int32_t max_len;       /* config['max_length'] = decoder positional table length, decoder.py:28       */
+    int32_t bos, eos, pad; /* config bos_token / eos_token / trg_pad_idx                                  */
+    int32_t dtype;         /* TXO_F32 | TXO_BF16                                                          */
+    int32_t max_batch;     /* capacity: images per call                                                   */
+    int32_t max_tokens;    /* capacity: encoder tokens per image (<= 1 + (canvas/16)^2); 0 = that maximum */
+} txo_config;
+
+/* OCRModel.__init__ / create_model (ocr_model.py:16-32,113-130): allocate the engine. */
+int txo_engine_create(const txo_config* cfg, txo_engine** out);
+void txo_engine_destroy(txo_engine* e);
+
+/* nn.Module.load_state_dict, one tensor at a time (key layout of OCRModel.state_dict()):
+ * `key` is the reference state_dict key, `data` HOST float32, `shape`/`ndim` its shape.  Aliased shared
+ * LayerNorm keys (layers.{s}.0.weight for every s, attention.py:200,221) may all be passed; they must
+ * carry identical values.  txo_engine_finalize_weights checks completeness and uploads. */
+int txo_engine_set_weight(txo_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim);
+int txo_engine_finalize_weights(txo_engine* e);
+
+/* VisionEncoder.forward (encoder.py:128-152): img_dev [B,C,H,W] -> enc_out_dev [B, 1+(H/16)(W/16), D]. */
+int txo_encode(txo_engine* e, const float* img_dev, int32_t B, int32_t C, int32_t H, int32_t W,
+               float* enc_out_dev, void* stream);
+
+/* Start a decode over `enc_dev` [B,N,D] (the `enc=` kwarg of decoder.generate / net, decoder.py:56,103):
+ * projects the cross-attention K/V of every decoder layer once (attention.py:125-126), clears the
+ * self-attention cache, position <- 0, current token <- bos. */
+int txo_decode_begin(txo_engine* e, const float* enc_dev, int32_t B, int32_t N, void* stream);
+
+/* One position of Transformer.forward in KV-cached form (decoder.py:41-67): feeds tok_in_dev[B] (NULL =
+ * the engine's current token: bos, or the previous step's argmax) at position t (t must equal the number
+ * of positions decoded since txo_decode_begin, or less to rewind), writes the position's logits
+ * [B,vocab] to logits_out_dev (may be NULL) and their argmax to tok_out_dev[B] (may be NULL). */
+int txo_decode_step(txo_engine* e, const int64_t* tok_in_dev, int32_t t, float* logits_out_dev,
+                    int64_t* tok_out_dev, void* stream);
+
+/* OCRModel.generate (ocr_model.py:46-66) + AutoRegressiveDecoder.generate (decoder.py:77-122), greedy:
+ * encode, then up to max_len steps; stops early only when EVERY row contains `eos` (pass eos < 0 for
+ * eos_tok=None).  tokens_out_dev is [B, max_len] int64 (row stride max_len); *n_steps_out (HOST) receives
+ * the number of valid columns -- the reference returns output[:, :n_steps].  logits_out_dev (may be
+ * NULL) is [B, max_len, vocab].  Requires max_len <= cfg.max_len (the reference would slide its window,
+ * decoder.py:99-100, which a KV cache cannot reproduce).  Synchronises the stream before returning. */
+int txo_generate(txo_engine* e, const float* img_dev, int32_t B, int32_t C, int32_t H, int32_t W,
+                 int32_t max_len, int32_t eos, int64_t* tokens_out_dev, int32_t* n_steps_out,
+                 float* logits_out_dev, void* stream);
+
+/* Same loop over a caller-provided encoder output (decoder.generate(start_tokens=[bos], enc=enc)). */
+int txo_generate_from_enc(txo_engine* e, const float* enc_dev, int32_t B, int32_t N, int32_t max_len,
+                          int32_t eos, int64_t* tokens_out_dev, int32_t* n_steps_out, float* logits_out_dev,
+                          void* stream);
+
+/* Timing hooks for bench.py: average duration (ms) of the decode-step cross-attention launches and of
+ * the encoder launches recorded with HIP events on the stream the kernels run on, since the last
+ * txo_profile_reset; *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,
+ * 1 = encoder (whole txo_encode), 2 = whole decode step. */
+int txo_profile_enable(txo_engine* e, int32_t on);
+int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count);
+
+const char* txo_last_error(void);
+const char* txo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXOCR_H */

@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 kernels (wave64, MFMA 16x16, LDS swizzles).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+
+namespace txo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+constexpr float LN_EPS = 1e-5f;         // nn.LayerNorm default (reference attention.py:200)
+constexpr float ATTN_SCALE = 0.125f;    // dim_head ** -0.5 with dim_head = 64 (attention.py:76,80)
+constexpr int DH = 64;
+
+// ---- element types ------------------------------------------------------------------
+// A "k-chunk" is 64 bytes of one operand row: 16 f32 or 32 bf16.  One 16-byte piece of it per
+// lane group (lane>>4) is exactly one MFMA operand fragment in both element types:
+//   f32 : 4 floats  -> four v_mfma_f32_16x16x4_f32   (k = 4*group + e, e = 0..3; A and B use the
+//                      same permuted k order, so the sum over k is unchanged)
+//   bf16: 8 bf16    -> one  v_mfma_f32_16x16x32_bf16 (k = 8*group + j)
+// C/D layout (both): col = lane & 15, row = (lane >> 4) * 4 + reg.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PER16 = 4;     // elements per 16 bytes
+    static constexpr int KCHUNK = 16;   // elements per 64-byte k-chunk
+    __device__ static inline float from_f32(float v) { return v; }
+    __device__ static inline float to_f32(float v) { return v; }
+};
+template <> struct Elem<__hip_bfloat16> {
+    static constexpr int PER16 = 8;
+    static constexpr int KCHUNK = 32;
+    __device__ static inline __hip_bfloat16 from_f32(float v) { return __float2bfloat16(v); }
+    __device__ static inline float to_f32(__hip_bfloat16 v) { return __bfloat162float(v); }
+};
+typedef __hip_bfloat16 bf16;
+
+template <typename T>
+__device__ inline void mma16(f32x4& acc, const u32x4& a, const u32x4& b);
+
+template <>
+__device__ inline void mma16<float>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+template <>
+__device__ inline void mma16<bf16>(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                  acc, 0, 0, 0);
+}
+
+// ---- wave reductions ------------------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reduce over the 16 lanes that share (lane >> 4)
+__device__ inline float row16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// reduce over the 4 lane groups (lanes l, l^16, l^32, l^48)
+__device__ inline float grp4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ inline float grp4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// exact-erf GELU (F.gelu default, reference attention.py:17) and sigmoid (nn.GLU, :98)
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// 128-byte LDS rows of 8 x 16-byte pieces, piece index XOR-swizzled with the row so that a
+// ds_read_b128 fragment read (16 rows x one piece per lane group) is bank-conflict free.
+__device__ inline int swz128(int row, int piece) { return row * 128 + ((piece ^ (row & 7)) << 4); }
+
+__device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+}  // namespace txo

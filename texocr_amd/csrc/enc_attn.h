@@ -1,0 +1,188 @@
+// Encoder self-attention (non-causal), flash-style, exact-f32 MFMA.
+// Reference: MultiHeadAttention.forward, model/attention.py:148-173 with causal=False and all-True masks:
+//   energy = q k^T * 0.125 ; softmax over keys ; out = attn v ; merge heads 'b h n d -> b n (h d)'.
+// The reference materialises (and clones twice) the [B,h,N,N] score tensor; here scores never leave
+// registers.
+//
+// Inputs q,k,v: head-major [B*heads][N][64] f32 (written by the QKV GEMM epilogue).  Output: [B*N][heads*64].
+//
+// gfx950 mapping.  Block = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries (two
+// 16-wide MFMA column tiles).  K/V stream through LDS in 64-key stages (double buffered, 64 KB).
+// S^T = K Q^T is computed with the key on the MFMA row and the query on the lane column, so that
+//  (1) the softmax statistics of a query live in one lane column (registers + 2 cross-group shuffles),
+//  (2) the P tile in its accumulator layout IS the B operand of O^T += V^T P^T (16x16x4: lane group g,
+//      register r holds key 4g+r; the V fragment is simply read for that same key) -- no LDS round trip
+//      and no lane movement for P.
+// MFMA: v_mfma_f32_16x16x4_f32, 64 per wave per 16 keys (32 for QK^T, 32 for PV) = the f32 matrix peak
+// rate; everything else (8 exps, 32 rescale FMAs, 20 LDS reads per 16 keys) hides behind it.
+// Bound: MFMA f32 (157 TF peak).
+#pragma once
+#include "common.h"
+
+namespace txo {
+
+constexpr int EA_QBLK = 128, EA_KSTAGE = 64;
+
+__device__ inline int swz256(int row, int piece) { return row * 256 + ((piece ^ (row & 15)) << 4); }
+
+template <typename TO>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ Q, const float* __restrict__ Kg,
+                                                       const float* __restrict__ Vg, TO* __restrict__ out, int N,
+                                                       int heads) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 256];   // [buf][K|V]
+    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
+    const int q0 = blockIdx.x * EA_QBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lg = lane >> 4;
+    const float* Qb = Q + (size_t)bh * N * DH;
+    const float* Kb = Kg + (size_t)bh * N * DH;
+    const float* Vb = Vg + (size_t)bh * N * DH;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query = lc, group lg) holds Q[query][16kc + 4lg + e]
+    u32x4 qf[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qrow = min(q0 + wave * 32 + qt * 16 + lc, N - 1);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            float4 t = *reinterpret_cast<const float4*>(Qb + (size_t)qrow * DH + kc * 16 + lg * 4);
+            t.x *= ATTN_SCALE; t.y *= ATTN_SCALE; t.z *= ATTN_SCALE; t.w *= ATTN_SCALE;   // exact (power of two)
+            qf[qt][kc] = __builtin_bit_cast(u32x4, t);
+        }
+    }
+
+    f32x4 o[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+
+    // staging: 64 keys x 256 B = 1024 16-byte pieces per operand, 4 per thread
+    u32x4 rk[4], rv[4];
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, piece = idx & 15;
+            const int key = min(s * EA_KSTAGE + row, N - 1);
+            rk[i] = ld16(Kb + (size_t)key * DH + piece * 4);
+            rv[i] = ld16(Vb + (size_t)key * DH + piece * 4);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 4, piece = idx & 15;
+            st16(&lds[buf][0][swz256(row, piece)], rk[i]);
+            st16(&lds[buf][1][swz256(row, piece)], rv[i]);
+        }
+    };
+
+    const int nstage = (N + EA_KSTAGE - 1) / EA_KSTAGE;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) load_stage(s + 1);
+        const unsigned char* Ks = lds[buf][0];
+        const unsigned char* Vs = lds[buf][1];
+
+        // ---- S^T for 64 keys x 32 queries ----
+        f32x4 sc[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            u32x4 kf[4];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) kf[kc] = ld16(Ks + swz256(kt * 16 + lc, kc * 4 + lg));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) mma16<float>(a, kf[kc], qf[qt][kc]);
+                sc[qt][kt] = a;
+            }
+        }
+        // keys past N only exist in the last stage
+        const int kbase = s * EA_KSTAGE;
+        if (kbase + EA_KSTAGE > N) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + kt * 16 + lg * 4 + r >= N) { sc[0][kt][r] = -1e30f; sc[1][kt][r] = -1e30f; }
+        }
+        // ---- online softmax (per query = per lane column; keys spread over regs and lane groups) ----
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = sc[qt][0][0];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
+            mx = grp4_max(mx);
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = expf(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float p = expf(sc[qt][kt][r] - m_new); sc[qt][kt][r] = p; ps += p; }
+            l_run[qt] = l_run[qt] * alpha + ps;          // per-lane partial; groups are summed at the end
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+        }
+        // ---- O^T += V^T P^T : A = V[key 16kt+4lg+r][d = 16dt+lc] (one float per lane), B = P regs ----
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = kt * 16 + lg * 4 + r;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int col = dt * 16 + lc;
+                    const float vv = *reinterpret_cast<const float*>(Vs + swz256(row, col >> 2) + (col & 3) * 4);
+                    o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, sc[0][kt][r], o[0][dt], 0, 0, 0);
+                    o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, sc[1][kt][r], o[1][dt], 0, 0, 0);
+                }
+            }
+        }
+        if (s + 1 < nstage) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise, transpose through LDS (wave-private 32 x 64 f32 tile), store whole 256-byte rows ----
+    float* tile = reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 64);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float inv = 1.0f / grp4_sum(l_run[qt]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(qt * 16 + lc) * 64 + ((dt * 16 + lg * 4 + r) ^ ((lc & 7) << 2))] = o[qt][dt][r] * inv;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes are done (wave-private tile)
+    const int inner = heads * DH;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, qq = idx >> 4, piece = idx & 15;
+        const int qrow = q0 + wave * 32 + qq;
+        if (qrow < N) {
+            const int c0 = (piece * 4) ^ ((qq & 7) << 2);
+            const float4 v4 = *reinterpret_cast<const float4*>(&tile[qq * 64 + c0]);
+            TO* dst = out + ((size_t)(b * N + qrow)) * inner + head * DH + piece * 4;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(dst) = v4;
+            } else {
+                union { bf16 h[4]; uint2 u; } t;
+                t.h[0] = __float2bfloat16(v4.x); t.h[1] = __float2bfloat16(v4.y);
+                t.h[2] = __float2bfloat16(v4.z); t.h[3] = __float2bfloat16(v4.w);
+                *reinterpret_cast<uint2*>(dst) = t.u;
+            }
+        }
+    }
+}
+
+}  // namespace txo

@@ -1,0 +1,577 @@
+// Engine + C ABI (include/texocr.h) for the MI355X-native OCRModel.generate() path.
+// Host side only orchestrates: all arithmetic is in the HIP kernels of this directory.
+#include "../../include/texocr.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "dec_attn.h"
+#include "dec_gemm.h"
+#include "enc_attn.h"
+#include "gemm_big.h"
+#include "rows.h"
+#include "step.h"
+
+namespace txo {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess)                                                                           \
+            return fail(TXO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
+    } while (0)
+
+struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
+
+// -------------------------------------------------------------------------------------------------
+struct EngineBase {
+    txo_config cfg{};
+    std::map<std::string, HostTensor> host;     // reference-keyed weights until finalize
+    bool ready = false;
+    virtual ~EngineBase() {}
+    virtual int finalize() = 0;
+    virtual int encode(const float* img, int B, int C, int H, int W, float* enc_out, hipStream_t s) = 0;
+    virtual int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) = 0;
+    virtual int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) = 0;
+    virtual int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
+                         int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) = 0;
+    virtual int profile_enable(int on) = 0;
+    virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
+};
+
+static std::vector<std::string> stack_kinds(bool dec, int layers) {
+    std::vector<std::string> k;
+    for (int l = 0; l < layers; ++l) {
+        k.push_back("self");
+        if (dec) k.push_back("cross");
+        k.push_back("mlp");
+    }
+    return k;
+}
+
+// rows [2X][K] -> groups of 32 rows: 16 "value" rows (g*16..) followed by their 16 "gate" rows (X + g*16..)
+static std::vector<float> interleave16(const std::vector<float>& w, int X, int K) {
+    std::vector<float> o((size_t)2 * X * K);
+    for (int g = 0; g < X / 16; ++g)
+        for (int h = 0; h < 2; ++h)
+            for (int r = 0; r < 16; ++r)
+                memcpy(&o[((size_t)g * 32 + h * 16 + r) * K], &w[((size_t)h * X + g * 16 + r) * K], sizeof(float) * K);
+    return o;
+}
+
+struct EventPool {
+    std::vector<hipEvent_t> ev; size_t used = 0;
+    hipEvent_t next() {
+        if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return nullptr; ev.push_back(e); }
+        return ev[used++];
+    }
+    ~EventPool() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
+template <typename T>
+struct Engine : EngineBase {
+    // ----- device weights -----
+    std::vector<void*> allocs;
+    struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr; };
+    struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr; };
+    float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
+    float *enc_g = nullptr, *enc_b = nullptr, *encn_g = nullptr, *encn_b = nullptr;
+    std::vector<AttnW> enc_attn; std::vector<MlpW> enc_mlp;
+    float *tok_emb = nullptr, *pos_emb = nullptr, *dec_g = nullptr, *dec_b = nullptr, *decn_g = nullptr, *decn_b = nullptr;
+    T* wlog = nullptr; float* blog = nullptr; T* wckv = nullptr;
+    std::vector<AttnW> dec_self, dec_cross; std::vector<MlpW> dec_mlp;
+    // ----- workspace -----
+    float *ex = nullptr, *ey = nullptr, *eqkv = nullptr, *eenc = nullptr; T *ez = nullptr, *eao = nullptr, *ehid = nullptr;
+    T* enc_t = nullptr;               // bf16 copy of the encoder output (A operand of the cross K/V GEMM)
+    T *ckv = nullptr, *skv = nullptr;  // cross [Ld][2][B*h][N][64], self [Ld][2][B*h][Tmax][64]
+    float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr;
+    int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
+    // ----- decode session -----
+    int sB = 0, sN = 0; bool session = false;
+    // ----- profiling -----
+    bool prof = false; EventPool pool;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_cross, ev_enc, ev_step;
+
+    int D, Ie, Id, Fe, Fd, V, Tmax, Nmax, Bmax;
+
+    ~Engine() override { for (void* p : allocs) (void)hipFree(p); }
+
+    template <typename U> int dalloc(U** p, size_t n) {
+        void* q = nullptr;
+        HIP_TRY(hipMalloc(&q, n * sizeof(U) + 256));
+        allocs.push_back(q);
+        *p = reinterpret_cast<U*>(q);
+        return 0;
+    }
+    int upload_f32(float** dst, const std::vector<float>& v) {
+        if (int r = dalloc(dst, v.size())) return r;
+        HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_T(T** dst, const std::vector<float>& v) {
+        if (int r = dalloc(dst, v.size())) return r;
+        if constexpr (sizeof(T) == 4) {
+            HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            std::vector<uint16_t> h(v.size());
+            for (size_t i = 0; i < v.size(); ++i) {      // round-to-nearest-even f32 -> bf16 (inputs are finite)
+                uint32_t u; memcpy(&u, &v[i], 4);
+                h[i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+            }
+            HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        return 0;
+    }
+
+    const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape) {
+        auto it = host.find(key);
+        if (it == host.end()) { g_err = "missing weight: " + key; return nullptr; }
+        if (it->second.shape != std::vector<int64_t>(shape)) { g_err = "wrong shape for " + key; return nullptr; }
+        return &it->second;
+    }
+
+    // shared LayerNorm of a stack: every alias layers.{s}.0.* that was provided must be identical
+    int shared_ln(const std::string& prefix, int n_sub, float** g, float** b) {
+        const HostTensor* g0 = get(prefix + ".layers.0.0.weight", {D});
+        const HostTensor* b0 = get(prefix + ".layers.0.0.bias", {D});
+        if (!g0 || !b0) return TXO_E_STATE;
+        for (int s = 1; s < n_sub; ++s)
+            for (const char* leaf : {"weight", "bias"}) {
+                auto it = host.find(prefix + ".layers." + std::to_string(s) + ".0." + leaf);
+                if (it == host.end()) continue;
+                const HostTensor& ref = (leaf[0] == 'w') ? *g0 : *b0;
+                if (it->second.data != ref.data)
+                    return fail(TXO_E_INVALID, prefix + ".layers." + std::to_string(s) + ".0." + leaf +
+                                " differs from layers.0.0: the reference shares ONE LayerNorm per stack");
+            }
+        if (int r = upload_f32(g, g0->data)) return r;
+        return upload_f32(b, b0->data);
+    }
+
+    int load_attn(const std::string& p, int inner, bool cross, AttnW* w, std::vector<float>* kv_concat) {
+        const HostTensor *q = get(p + ".q.weight", {inner, D}), *k = get(p + ".k.weight", {inner, D}),
+                         *v = get(p + ".v.weight", {inner, D}), *wo = get(p + ".fc_out.0.weight", {2 * D, inner}),
+                         *bo = get(p + ".fc_out.0.bias", {2 * D});
+        if (!q || !k || !v || !wo || !bo) return TXO_E_STATE;
+        if (cross) {
+            if (int r = upload_T(&w->wq, q->data)) return r;
+            kv_concat->insert(kv_concat->end(), k->data.begin(), k->data.end());
+            kv_concat->insert(kv_concat->end(), v->data.begin(), v->data.end());
+        } else {
+            std::vector<float> cat(q->data);
+            cat.insert(cat.end(), k->data.begin(), k->data.end());
+            cat.insert(cat.end(), v->data.begin(), v->data.end());
+            if (int r = upload_T(&w->wqkv, cat)) return r;
+        }
+        if (int r = upload_T(&w->wo, interleave16(wo->data, D, inner))) return r;
+        return upload_f32(&w->bo, interleave16(bo->data, D, 1));
+    }
+    int load_mlp(const std::string& p, int F, MlpW* w) {
+        const HostTensor *w1 = get(p + ".fc_in.fc.weight", {2 * F, D}), *b1 = get(p + ".fc_in.fc.bias", {2 * F}),
+                         *w2 = get(p + ".fc_out.weight", {D, F}), *b2 = get(p + ".fc_out.bias", {D});
+        if (!w1 || !b1 || !w2 || !b2) return TXO_E_STATE;
+        if (int r = upload_T(&w->w1, interleave16(w1->data, F, D))) return r;
+        if (int r = upload_f32(&w->b1, interleave16(b1->data, F, 1))) return r;
+        if (int r = upload_T(&w->w2, w2->data)) return r;
+        return upload_f32(&w->b2, b2->data);
+    }
+
+    int finalize() override {
+        if (ready) return fail(TXO_E_STATE, "weights already finalized");
+        const txo_config& c = cfg;
+        const int G = c.canvas / 16;
+        const HostTensor *t;
+        if (!(t = get("encoder.cls_token", {1, 1, D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&cls, t->data)) return r;
+        if (!(t = get("encoder.pos_embed", {1, 1 + G * G, D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&pos, t->data)) return r;
+        if (!(t = get("encoder.patch_embed.proj.weight", {D, c.in_channels, 16, 16}))) return TXO_E_STATE;
+        if (int r = upload_T(&patch_w, t->data)) return r;
+        if (!(t = get("encoder.patch_embed.proj.bias", {D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&patch_b, t->data)) return r;
+        if (int r = shared_ln("encoder.attn_layers", 2 * c.enc_layers, &enc_g, &enc_b)) return r;
+        enc_attn.resize(c.enc_layers); enc_mlp.resize(c.enc_layers);
+        for (int l = 0; l < c.enc_layers; ++l) {
+            const std::string p = "encoder.attn_layers.layers.";
+            if (int r = load_attn(p + std::to_string(2 * l) + ".1", Ie, false, &enc_attn[l], nullptr)) return r;
+            if (int r = load_mlp(p + std::to_string(2 * l + 1) + ".1", Fe, &enc_mlp[l])) return r;
+        }
+        if (!(t = get("encoder.norm.weight", {D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&encn_g, t->data)) return r;
+        if (!(t = get("encoder.norm.bias", {D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&encn_b, t->data)) return r;
+
+        if (!(t = get("decoder.net.token_embedding.weight", {V, D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&tok_emb, t->data)) return r;
+        if (!(t = get("decoder.net.pos_embedding.embedding.weight", {Tmax, D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&pos_emb, t->data)) return r;
+        if (int r = shared_ln("decoder.net.attn_layers", 3 * c.dec_layers, &dec_g, &dec_b)) return r;
+        dec_self.resize(c.dec_layers); dec_cross.resize(c.dec_layers); dec_mlp.resize(c.dec_layers);
+        std::vector<float> kv_concat;
+        for (int l = 0; l < c.dec_layers; ++l) {
+            const std::string p = "decoder.net.attn_layers.layers.";
+            if (int r = load_attn(p + std::to_string(3 * l) + ".1", Id, false, &dec_self[l], nullptr)) return r;
+            if (int r = load_attn(p + std::to_string(3 * l + 1) + ".1", Id, true, &dec_cross[l], &kv_concat)) return r;
+            if (int r = load_mlp(p + std::to_string(3 * l + 2) + ".1", Fd, &dec_mlp[l])) return r;
+        }
+        if (int r = upload_T(&wckv, kv_concat)) return r;
+        if (!(t = get("decoder.net.norm.weight", {D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&decn_g, t->data)) return r;
+        if (!(t = get("decoder.net.norm.bias", {D}))) return TXO_E_STATE;
+        if (int r = upload_f32(&decn_b, t->data)) return r;
+        if (!(t = get("decoder.net.to_logits.weight", {V, D}))) return TXO_E_STATE;
+        if (int r = upload_T(&wlog, t->data)) return r;
+        if (!(t = get("decoder.net.to_logits.bias", {V}))) return TXO_E_STATE;
+        if (int r = upload_f32(&blog, t->data)) return r;
+        host.clear();
+        ready = true;
+        return 0;
+    }
+
+    int init() {
+        const txo_config& c = cfg;
+        D = c.embed_dim; Ie = c.enc_heads * DH; Id = c.dec_heads * DH; Fe = c.enc_exp * D; Fd = c.dec_exp * D;
+        V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
+        const int G = c.canvas / 16;
+        Nmax = c.max_tokens > 0 ? c.max_tokens : 1 + G * G;
+        const size_t M = (size_t)Bmax * Nmax;
+        const int Imax = Ie > Id ? Ie : Id, Fmax = Fe > Fd ? Fe : Fd;
+        if (int r = dalloc(&ex, M * D)) return r;
+        if (int r = dalloc(&ey, M * D)) return r;
+        if (int r = dalloc(&ez, M * D)) return r;
+        if (int r = dalloc(&eenc, M * D)) return r;
+        if (int r = dalloc(&enc_t, M * D)) return r;
+        if (int r = dalloc(&eqkv, 3 * M * Ie)) return r;
+        if (int r = dalloc(&eao, M * Ie)) return r;
+        if (int r = dalloc(&ehid, M * Fe)) return r;
+        if (int r = dalloc(&ckv, (size_t)c.dec_layers * 2 * M * Id)) return r;
+        if (int r = dalloc(&skv, (size_t)c.dec_layers * 2 * Bmax * Id * Tmax)) return r;
+        if (int r = dalloc(&dx, (size_t)Bmax * D)) return r;
+        if (int r = dalloc(&dy, (size_t)Bmax * D)) return r;
+        if (int r = dalloc(&dq, (size_t)Bmax * Imax)) return r;
+        if (int r = dalloc(&dao, (size_t)Bmax * Imax)) return r;
+        if (int r = dalloc(&dhid, (size_t)Bmax * Fmax)) return r;
+        if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
+        if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
+        if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
+        if (int r = dalloc(&done_flag, (size_t)Tmax)) return r;
+        if (int r = dalloc(&st, 1)) return r;
+        HIP_TRY(hipMemset(st, 0, sizeof(StepState)));
+        return 0;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    template <int MODE, typename TZ>
+    void launch_ln(hipStream_t s, const float* in, float* x_out, TZ* z_out, const float* g, const float* b, int rows) {
+        const dim3 grid((rows + 3) / 4), blk(256);
+        if (D == 256) hipLaunchKernelGGL((ln_rows_kernel<TZ, 1, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
+        else if (D == 512) hipLaunchKernelGGL((ln_rows_kernel<TZ, 2, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
+        else if (D == 768) hipLaunchKernelGGL((ln_rows_kernel<TZ, 3, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
+        else hipLaunchKernelGGL((ln_rows_generic_kernel<TZ, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, D);
+    }
+
+    int encode(const float* img, int B, int C, int H, int W, float* enc_out, hipStream_t s) override {
+        if (!ready) return fail(TXO_E_STATE, "weights not finalized");
+        if (C != cfg.in_channels) return fail(TXO_E_INVALID, "image channel count does not match in_channels");
+        if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail(TXO_E_INVALID, "image height/width must be positive multiples of 16");
+        if (H > cfg.canvas || W > cfg.canvas) return fail(TXO_E_INVALID, "image larger than the position-embedding canvas");
+        const int h = H / 16, w = W / 16, hw = h * w, N = hw + 1;
+        if (B < 1 || B > Bmax) return fail(TXO_E_INVALID, "batch exceeds engine max_batch");
+        if (N > Nmax) return fail(TXO_E_INVALID, "token count exceeds engine max_tokens");
+        const int M = B * N, G = cfg.canvas / 16;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+
+        hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, ex, cls, pos, B, N, D);
+        launch_gemm_big<T>(s, LoadPatch<T>{img, C, H, W, hw, w}, patch_w, B * hw, D, C * 256,
+                           EpiPatch{ex, patch_b, pos, D, hw, w, G});
+        const size_t hs = (size_t)M * Ie;      // one of q/k/v, head-major [B*heads][N][64]
+        for (int l = 0; l < cfg.enc_layers; ++l) {
+            if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
+            else launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
+            launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
+                               EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N});
+            hipLaunchKernelGGL((enc_attn_kernel<T>), dim3((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads), dim3(256), 0,
+                               s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N, cfg.enc_heads);
+            launch_gemm_big<T>(s, LoadPlain<T>{eao, Ie}, enc_attn[l].wo, M, 2 * D, Ie,
+                               EpiGluRes{ey, ex, enc_attn[l].bo, D});
+            launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
+            launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
+            launch_gemm_big<T>(s, LoadPlain<T>{ehid, Fe}, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, ex, enc_mlp[l].b2, D});
+        }
+        launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M);
+        if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) override {
+        if (!ready) return fail(TXO_E_STATE, "weights not finalized");
+        if (B < 1 || B > Bmax) return fail(TXO_E_INVALID, "batch exceeds engine max_batch");
+        if (N < 1 || N > Nmax) return fail(TXO_E_INVALID, "token count exceeds engine max_tokens");
+        const int M = B * N;
+        const T* a_enc;
+        if constexpr (sizeof(T) == 4) a_enc = enc;
+        else {
+            const size_t n4 = (size_t)M * D / 4;
+            hipLaunchKernelGGL((cast_rows_kernel<T>), dim3((n4 + 255) / 256), dim3(256), 0, s, enc, enc_t, n4);
+            a_enc = enc_t;
+        }
+        // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D]
+        launch_gemm_big<T>(s, LoadPlain<T>{a_enc, D}, wckv, M, cfg.dec_layers * 2 * Id, D,
+                           EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, N});
+        const int n = B > Tmax ? B : Tmax;
+        hipLaunchKernelGGL(reset_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, cur_tok, eos_seen, done_flag,
+                           B, Tmax, cfg.bos, eos);
+        HIP_TRY(hipGetLastError());
+        sB = B; sN = N; session = true;
+        return 0;
+    }
+
+    template <int PRO, int EPI>
+    int launch_dec_gemm(hipStream_t s, DecGemmArgs<T> a) {
+        const bool has_pro = PRO != PRO_NONE;
+        int MT = a.rows <= 16 ? 1 : (a.rows <= 32 ? 2 : 4);
+        while (has_pro && MT > 1 && (size_t)16 * MT * a.K * sizeof(T) > 128 * 1024) MT >>= 1;
+        const dim3 grid((a.N + 31) / 32, (a.rows + 16 * MT - 1) / (16 * MT)), blk(256);
+        const bool big = has_pro && a.K > 256;
+#define TXO_DG(MTV, NVV)                                                                              \
+        do {                                                                                          \
+            auto kern = dec_gemm_kernel<T, MTV, PRO, EPI, NVV>;                                       \
+            const size_t lds = dec_gemm_lds_bytes<T, MTV>(a.K, has_pro);                              \
+            if (lds > 64 * 1024)                                                                      \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
+            hipLaunchKernelGGL(kern, grid, blk, lds, s, a);                                           \
+        } while (0)
+        if (big) { if (MT == 1) TXO_DG(1, 12); else if (MT == 2) TXO_DG(2, 12); else TXO_DG(4, 12); }
+        else     { if (MT == 1) TXO_DG(1, 4);  else if (MT == 2) TXO_DG(2, 4);  else TXO_DG(4, 4); }
+#undef TXO_DG
+        return 0;
+    }
+
+    void launch_dec_attn(hipStream_t s, const T* K, const T* Vv, int lmax, int len, bool is_cross) {
+        DecAttnArgs<T> a{dq, K, Vv, dao, cfg.dec_heads, lmax, len, &st->t};
+        const int L = len >= 0 ? len : Tmax;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && is_cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+        hipLaunchKernelGGL((dec_attn_kernel<T>), dim3(sB * cfg.dec_heads), dim3(256), (size_t)L * sizeof(float), s, a);
+        if (prof && is_cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
+    }
+
+    // one decode position on the stream; tokens/logits destinations are per call
+    int enqueue_step(hipStream_t s, int64_t* tokens_out, int out_stride, float* logits_out, int eos) {
+        const int B = sB, N = sN;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+        DecGemmArgs<T> base{};
+        base.rows = B; base.gamma = dec_g; base.beta = dec_b; base.t_ptr = &st->t; base.D = D;
+        base.tok = cur_tok; base.tok_emb = tok_emb; base.pos_emb = pos_emb;
+        base.q_out = dq; base.inner = Id; base.heads = cfg.dec_heads; base.tmax = Tmax;
+        const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)B * N * Id;
+        for (int l = 0; l < cfg.dec_layers; ++l) {
+            T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
+            {   // causal self attention
+                DecGemmArgs<T> a = base; a.N = 3 * Id; a.K = D; a.W = dec_self[l].wqkv; a.y = dy; a.x_out = dx;
+                a.k_cache = kc; a.v_cache = vc;
+                if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_QKV>(s, a) : launch_dec_gemm<PRO_LN2, EPI_QKV>(s, a))) return r;
+                launch_dec_attn(s, kc, vc, Tmax, -1, false);
+                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = dao;
+                o.resid = dx; o.y_out = dy;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+            }
+            {   // cross attention over the cached encoder projections
+                DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy; a.x_out = dx;
+                if (int r = launch_dec_gemm<PRO_LN2, EPI_Q>(s, a)) return r;
+                launch_dec_attn(s, ckv + (size_t)(2 * l) * cross_stride, ckv + (size_t)(2 * l + 1) * cross_stride, N, N, true);
+                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = dao;
+                o.resid = dx; o.y_out = dy;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+            }
+            {   // GeGLU feed-forward
+                DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = dy; a.x_out = dx;
+                a.h_out = dhid; a.F = Fd;
+                if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
+                DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = dhid;
+                o.resid = dx; o.y_out = dy;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, o)) return r;
+            }
+        }
+        DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.y = dy; f.gamma = decn_g; f.beta = decn_b;
+        f.logits = dlogits;
+        if (int r = launch_dec_gemm<PRO_LNF, EPI_LOGITS>(s, f)) return r;
+        StepArgs sa{dlogits, V, B, cur_tok, tokens_out, out_stride, logits_out, st, eos_seen, done_flag, eos};
+        hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
+        if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
+        return 0;
+    }
+
+    int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) override {
+        if (!session) return fail(TXO_E_STATE, "txo_decode_begin has not been called");
+        if (t < 0 || t >= Tmax)
+            return fail(TXO_E_INVALID, "position outside the decoder's positional table (the reference would slide its "
+                                       "window, decoder.py:99-100; a KV cache cannot reproduce that)");
+        if (tok_in) HIP_TRY(hipMemcpyAsync(cur_tok, tok_in, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, t);
+        if (int r = enqueue_step(s, nullptr, 0, nullptr, -1)) return r;
+        if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, dlogits, sizeof(float) * sB * V, hipMemcpyDeviceToDevice, s));
+        if (tok_out) HIP_TRY(hipMemcpyAsync(tok_out, cur_tok, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
+                 int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) override {
+        if (max_len < 1) return fail(TXO_E_INVALID, "max_len must be >= 1");
+        if (max_len > Tmax)
+            return fail(TXO_E_INVALID, "max_len exceeds the decoder's max_length: the reference would slide its window "
+                                       "(decoder.py:99-100), which the KV-cached path does not reproduce");
+        if (img) {
+            if (int r = encode(img, B, C, H, W, eenc, s)) return r;
+            enc = eenc; N = 1 + (H / 16) * (W / 16);
+        }
+        if (int r = decode_begin(enc, B, N, eos, s)) return r;   // eos also decides whether the BOS column counts
+        std::vector<int> flags(max_len);
+        const int CHUNK = 32;
+        int steps = max_len;
+        for (int t = 0; t < max_len; ++t) {
+            if (int r2 = enqueue_step(s, tokens_out, max_len, logits_out, eos)) return r2;
+            if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
+                const int lo = (t / CHUNK) * CHUNK;
+                HIP_TRY(hipMemcpyAsync(flags.data() + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                bool stop = false;
+                for (int i = lo; i <= t; ++i) if (flags[i]) { steps = i + 1; stop = true; break; }
+                if (stop) break;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
+        if (n_steps) *n_steps = steps;
+        return 0;
+    }
+
+    int profile_enable(int on) override {
+        prof = on != 0;
+        ev_cross.clear(); ev_enc.clear(); ev_step.clear(); pool.used = 0;
+        return 0;
+    }
+    int profile_read(int kind, double* avg_ms, int64_t* count) override {
+        auto& v = kind == 0 ? ev_cross : (kind == 1 ? ev_enc : ev_step);
+        double tot = 0; int64_t n = 0;
+        for (auto& p : v) {
+            float ms = 0;
+            if (hipEventSynchronize(p.second) != hipSuccess) continue;
+            if (hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess) continue;
+            tot += ms; ++n;
+        }
+        if (avg_ms) *avg_ms = n ? tot / n : 0.0;
+        if (count) *count = n;
+        return 0;
+    }
+};
+
+static int validate(const txo_config& c) {
+    if (c.canvas <= 0 || c.canvas % 16) return fail(TXO_E_INVALID, "canvas must be a positive multiple of 16");
+    if (c.embed_dim < 64 || c.embed_dim % 64 || c.embed_dim > 768)
+        return fail(TXO_E_INVALID, "embed_dim must be a multiple of 64 in [64, 768]");
+    if (c.enc_heads < 1 || c.dec_heads < 1 || c.enc_layers < 1 || c.dec_layers < 1)
+        return fail(TXO_E_INVALID, "heads and layers must be >= 1");
+    if (c.enc_exp < 1 || c.dec_exp < 1 || (c.enc_exp * c.embed_dim) % 64 || (c.dec_exp * c.embed_dim) % 64)
+        return fail(TXO_E_INVALID, "FFN width must be a multiple of 64");
+    if (c.in_channels < 1 || c.vocab < 2 || c.max_len < 1) return fail(TXO_E_INVALID, "bad in_channels / vocab / max_len");
+    if (c.bos < 0 || c.bos >= c.vocab) return fail(TXO_E_INVALID, "bos token outside the vocabulary");
+    if (c.max_batch < 1 || c.max_batch > 65535) return fail(TXO_E_INVALID, "max_batch must be in [1, 65535]");
+    const int G = c.canvas / 16;
+    if (c.max_tokens < 0 || c.max_tokens > 1 + G * G) return fail(TXO_E_INVALID, "max_tokens exceeds 1 + (canvas/16)^2");
+    if (c.dtype != TXO_F32 && c.dtype != TXO_BF16) return fail(TXO_E_INVALID, "dtype must be TXO_F32 or TXO_BF16");
+    return 0;
+}
+
+}  // namespace txo
+
+using namespace txo;
+
+struct txo_engine { std::unique_ptr<EngineBase> impl; };
+
+extern "C" {
+
+int txo_engine_create(const txo_config* cfg, txo_engine** out) {
+    if (!cfg || !out) return fail(TXO_E_INVALID, "null argument");
+    if (int r = validate(*cfg)) return r;
+    std::unique_ptr<EngineBase> impl;
+    int r;
+    if (cfg->dtype == TXO_F32) { auto* e = new Engine<float>(); e->cfg = *cfg; impl.reset(e); r = e->init(); }
+    else { auto* e = new Engine<bf16>(); e->cfg = *cfg; impl.reset(e); r = e->init(); }
+    if (r) return r;
+    *out = new txo_engine{std::move(impl)};
+    return 0;
+}
+
+void txo_engine_destroy(txo_engine* e) { delete e; }
+
+int txo_engine_set_weight(txo_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!e || !key || !data || !shape || ndim < 1 || ndim > 4) return fail(TXO_E_INVALID, "bad argument");
+    if (e->impl->ready) return fail(TXO_E_STATE, "weights already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] < 1) return fail(TXO_E_INVALID, "bad shape"); t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    e->impl->host[key] = std::move(t);
+    return 0;
+}
+
+int txo_engine_finalize_weights(txo_engine* e) {
+    if (!e) return fail(TXO_E_INVALID, "null engine");
+    int r = e->impl->finalize();
+    if (r == TXO_E_STATE && g_err.empty()) g_err = "missing weights";
+    return r;
+}
+
+int txo_encode(txo_engine* e, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, float* enc_out, void* stream) {
+    if (!e || !img || !enc_out) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->encode(img, B, C, H, W, enc_out, (hipStream_t)stream);
+}
+
+int txo_decode_begin(txo_engine* e, const float* enc, int32_t B, int32_t N, void* stream) {
+    if (!e || !enc) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->decode_begin(enc, B, N, e->impl->cfg.eos, (hipStream_t)stream);
+}
+
+int txo_decode_step(txo_engine* e, const int64_t* tok_in, int32_t t, float* logits_out, int64_t* tok_out, void* stream) {
+    if (!e) return fail(TXO_E_INVALID, "null engine");
+    return e->impl->decode_step(tok_in, t, logits_out, tok_out, (hipStream_t)stream);
+}
+
+int txo_generate(txo_engine* e, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t max_len,
+                 int32_t eos, int64_t* tokens_out, int32_t* n_steps, float* logits_out, void* stream) {
+    if (!e || !img || !tokens_out) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->generate(img, nullptr, B, C, H, W, 0, max_len, eos, tokens_out, n_steps, logits_out, (hipStream_t)stream);
+}
+
+int txo_generate_from_enc(txo_engine* e, const float* enc, int32_t B, int32_t N, int32_t max_len, int32_t eos,
+                          int64_t* tokens_out, int32_t* n_steps, float* logits_out, void* stream) {
+    if (!e || !enc || !tokens_out) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->generate(nullptr, enc, B, 0, 0, 0, N, max_len, eos, tokens_out, n_steps, logits_out, (hipStream_t)stream);
+}
+
+int txo_profile_enable(txo_engine* e, int32_t on) { return e ? e->impl->profile_enable(on) : fail(TXO_E_INVALID, "null engine"); }
+int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count) {
+    return e ? e->impl->profile_read(kind, avg_ms, count) : fail(TXO_E_INVALID, "null engine");
+}
+
+const char* txo_last_error(void) { return g_err.c_str(); }
+const char* txo_version(void) { return "texocr-amd 0.1 (gfx950)"; }
+
+}  // extern "C"

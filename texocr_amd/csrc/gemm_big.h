@@ -1,0 +1,206 @@
+// Large-M GEMM for the encoder side of OCRModel.generate():  C[M,N] = A[M,K] * W[N,K]^T (+ epilogue).
+//
+// One kernel template, used for: patch embedding (reference model/encoder.py:25-28, A gathered
+// straight from the NCHW image -- no im2col buffer), q/k/v projection (model/attention.py:124-127,
+// epilogue scatters into head-major [B,heads,N,64]), gated output projection (:96-99,180, epilogue =
+// bias + GLU + residual), GeGLU FFN-in (:15-17) and FFN-out (:63-67), and the one-off cross-attention
+// K/V projection of the encoder output for every decoder layer (:125-126).
+//
+// gfx950 mapping: 256 threads = 4 waves as 2x2, block tile 128x128, wave tile 64x64 = 4x4 MFMA 16x16
+// tiles (64 accumulator VGPRs).  K is consumed in 128-byte stages (32 f32 / 64 bf16 per row), staged
+// global -> VGPR -> LDS with the next stage's global loads in flight behind the current stage's MFMAs;
+// LDS rows are 128 B with an XOR piece swizzle so the ds_read_b128 fragment reads are conflict free.
+// Weights are [N][K] (K contiguous) exactly as nn.Linear stores them, so A and W stage identically.
+// Bound: MFMA (f32-in MFMA = 157 TF peak in fp32 parity mode, bf16 MFMA = 2.5 PF in bf16 mode).
+#pragma once
+#include "common.h"
+
+namespace txo {
+
+constexpr int GB_BM = 128, GB_BN = 128, GB_THREADS = 256, GB_STAGE_BYTES = 128;
+
+// ---------------- A loaders: return 16 bytes (PER16 elements of T) of row m at element k ----------
+template <typename T> struct LoadPlain {
+    const T* A; int lda;
+    __device__ inline u32x4 operator()(int m, int k) const { return ld16(A + (size_t)m * lda + k); }
+};
+
+// patch rows: m = (b, pr, pc), k = (c, py, px) -> img[b][c][pr*16+py][pc*16+px]  (fp32 NCHW image)
+template <typename T> struct LoadPatch {
+    const float* img; int C, H, W, hw, w;   // hw = patches per image, w = patches per row
+    __device__ inline u32x4 operator()(int m, int k) const {
+        int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
+        int c = k >> 8, py = (k >> 4) & 15, px = k & 15;
+        const float* src = img + (((size_t)b * C + c) * H + pr * 16 + py) * W + pc * 16 + px;
+        if constexpr (sizeof(T) == 4) {
+            return ld16(src);
+        } else {
+            float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+            union { bf16 h[8]; u32x4 v; } u;
+            u.h[0] = __float2bfloat16(lo.x); u.h[1] = __float2bfloat16(lo.y); u.h[2] = __float2bfloat16(lo.z);
+            u.h[3] = __float2bfloat16(lo.w); u.h[4] = __float2bfloat16(hi.x); u.h[5] = __float2bfloat16(hi.y);
+            u.h[6] = __float2bfloat16(hi.z); u.h[7] = __float2bfloat16(hi.w);
+            return u.v;
+        }
+    }
+};
+
+// ---------------- epilogues: called once per (16-row, 16/32-col) accumulator group ---------------
+// Each gets (m, n, v) for plain tiles or (m, j, value, gate) for interleaved GLU pairs.
+template <typename T> struct EpiStore {           // out[m][n] = acc (+ bias)
+    T* out; int ldo; const float* bias;
+    static constexpr bool PAIRED = false;
+    __device__ inline void operator()(int m, int n, float v) const {
+        if (bias) v += bias[n];
+        out[(size_t)m * ldo + n] = Elem<T>::from_f32(v);
+    }
+};
+template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
+    T* base; size_t which_stride; int inner, heads, ntok;
+    static constexpr bool PAIRED = false;
+    __device__ inline void operator()(int m, int n, float v) const {
+        int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;
+        int b = m / ntok, t = m - b * ntok;
+        base[which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d] = Elem<T>::from_f32(v);
+    }
+};
+struct EpiGluRes {                                // y[m][j] = (v+bv) * sigmoid(g+bg) + resid[m][j]   (fp32 stream)
+    float* y; const float* resid; const float* bias; int D;   // bias is in the interleaved order
+    static constexpr bool PAIRED = true;
+    __device__ inline void operator()(int m, int j, int nv, int ng, float v, float g) const {
+        v += bias[nv]; g += bias[ng];
+        y[(size_t)m * D + j] = v * sigmoidf(g) + resid[(size_t)m * D + j];
+    }
+};
+template <typename T> struct EpiGeglu {           // h[m][j] = (v+bv) * gelu(g+bg)
+    T* h; const float* bias; int F;
+    static constexpr bool PAIRED = true;
+    __device__ inline void operator()(int m, int j, int nv, int ng, float v, float g) const {
+        v += bias[nv]; g += bias[ng];
+        h[(size_t)m * F + j] = Elem<T>::from_f32(v * gelu_erf(g));
+    }
+};
+struct EpiBiasRes {                               // y[m][n] = acc + bias[n] + resid[m][n]
+    float* y; const float* resid; const float* bias; int D;
+    static constexpr bool PAIRED = false;
+    __device__ inline void operator()(int m, int n, float v) const {
+        y[(size_t)m * D + n] = v + bias[n] + resid[(size_t)m * D + n];
+    }
+};
+struct EpiPatch {                                 // x[b][1+p][n] = acc + bias[n] + pos[1 + pr*G + pc][n]
+    float* x; const float* bias; const float* pos; int D, hw, w, G;
+    static constexpr bool PAIRED = false;
+    __device__ inline void operator()(int m, int n, float v) const {
+        int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
+        x[((size_t)b * (hw + 1) + 1 + p) * D + n] = v + bias[n] + pos[(size_t)(1 + pr * G + pc) * D + n];
+    }
+};
+
+template <typename T, class ALoad, class Epi>
+__global__ __launch_bounds__(GB_THREADS) void gemm_big_kernel(ALoad aload, const T* __restrict__ W, int M, int N,
+                                                              int K, int tiles_n, int n_tiles, Epi epi) {
+    constexpr int PER16 = Elem<T>::PER16;
+    constexpr int STAGE_K = GB_STAGE_BYTES / sizeof(T);
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][GB_BM * 128];   // [buf][A|W][row*128]
+
+    // XCD-aware tile order: blocks that share an XCD (blockIdx % 8) walk consecutive tiles of one
+    // A row panel, so the panel is fetched into that XCD's L2 once (speed only; bijective remap).
+    int bid = blockIdx.x;
+    {
+        int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * GB_BM, n0 = tile_n * GB_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // staging map: thread loads rows srow + 32*i (i<4), 16-byte piece spiece of the 128-byte stage row
+    const int srow = tid >> 3, spiece = tid & 7;
+    u32x4 ra[4], rw[4];
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+    auto load_stage = [&](int kt) {
+        const int k = kt * STAGE_K + spiece * PER16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + srow + 32 * i, n = n0 + srow + 32 * i;
+            ra[i] = (m < M) ? aload(m, k) : zero;
+            rw[i] = (n < N) ? ld16(W + (size_t)n * K + k) : zero;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = srow + 32 * i;
+            st16(&lds[buf][0][swz128(row, spiece)], ra[i]);
+            st16(&lds[buf][1][swz128(row, spiece)], rw[i]);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / STAGE_K;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_stage(kt + 1);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {          // two 64-byte k-chunks per stage
+            u32x4 fa[4], fw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = ld16(&lds[buf][0][swz128(wm + 16 * i + lr, kc * 4 + lg)]);
+                fw[i] = ld16(&lds[buf][1][swz128(wn + 16 * i + lr, kc * 4 + lg)]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], fa[i], fw[j]);
+        }
+        if (kt + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + 16 * i + lg * 4 + r;
+            if (m >= M) continue;
+            if constexpr (Epi::PAIRED) {
+                // columns interleaved in groups of 16: [16 value | 16 gate] per 32 weight rows
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int nv = n0 + wn + 32 * jp + lr, ng = nv + 16;
+                    if (ng < N) epi(m, (nv >> 5) * 16 + lr, nv, ng, acc[i][2 * jp][r], acc[i][2 * jp + 1][r]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn + 16 * j + lr;
+                    if (n < N) epi(m, n, acc[i][j][r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, class ALoad, class Epi>
+inline void launch_gemm_big(hipStream_t s, ALoad aload, const T* W, int M, int N, int K, Epi epi) {
+    const int tiles_m = (M + GB_BM - 1) / GB_BM, tiles_n = (N + GB_BN - 1) / GB_BN;
+    const int n_tiles = tiles_m * tiles_n;
+    hipLaunchKernelGGL((gemm_big_kernel<T, ALoad, Epi>), dim3(n_tiles), dim3(GB_THREADS), 0, s, aload, W, M, N, K,
+                       tiles_n, n_tiles, epi);
+}
+
+}  // namespace txo
