@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of OCRModel.generate() on synthetic 3x224x672 batches, greedy,
+max_len=256 (BASELINE.json configs[1]: config.yml dims, batch 64 per GPU).
+
+A "step" is one generate() call over one batch: ViT patch-embed + encoder stack, cross-K/V projection,
+256 KV-cached decode steps, and (N>1) the RCCL all-gather of the token ids.  Inputs are resident in HBM
+before the timed region.  One process per GPU (the driver launches torch.distributed.run for N>1); rank 0
+prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     -- decode-step cross-attention kernel (the HBM-bound kernel north_star names): algorithmic
+                  bytes per launch = B*heads*2*N*64*sizeof(dtype), divided by the kernel's average launch
+                  duration measured with HIP events on the engine's stream in a separate profiled pass
+                  (event pairs around each launch; not part of the timed region).
+  cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") in recompute mode = the reference's algorithm
+                  (no KV cache), timed on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=224)
+    ap.add_argument("--width", type=int, default=672)
+    ap.add_argument("--max-len", type=int, default=256)
+    ap.add_argument("--dtype", default=os.environ.get("TEXOCR_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(dims, sd_np, a):
+    """Reference algorithm (full-prefix recompute, cross K/V re-projected every step) on the host CPU."""
+    import torch
+    from oracle import cpu_ref
+    from texocr_amd import synth
+    b = a.cpu_sample_batch
+    img = torch.from_numpy(synth.synth_images(b, dims.in_channels, a.height, a.width, seed=1234))
+    sd = cpu_ref.to_torch_sd(sd_np)
+    cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, 4)            # warm the thread pool
+    t0 = time.perf_counter()
+    toks = cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, a.max_len)
+    dt = time.perf_counter() - t0
+    assert toks.shape[1] == a.max_len
+    return {"value": round(b / dt, 4), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"oracle recompute mode (reference algorithm, no KV cache), {b} images {dims.in_channels}x{a.height}x{a.width}, "
+                      f"{a.max_len} greedy steps, {dt:.1f} s wall, torch CPU fp32"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from texocr_amd.config import Dims
+    from texocr_amd import synth
+    from texocr_amd.model import model_from_dims
+    from texocr_amd.dist import all_gather_rows
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    dims = Dims(canvas=max(a.height, a.width))          # config.yml dims, PatchEmbedding front end, C=3
+    sd_np = synth.synth_state_dict(dims, 0)
+    model = model_from_dims(dims, dtype=a.dtype, max_batch=a.batch, max_tokens=dims.n_tokens(a.height, a.width))
+    model.load_state_dict(sd_np)
+    eng = model._engine
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = [torch.rand((a.batch, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
+            for _ in range(2)]
+    counts = [a.batch] * world
+
+    def step(i):
+        toks = model.generate(imgs[i & 1], a.max_len)                    # eos never fires with random weights
+        if toks.shape[1] != a.max_len:
+            raise RuntimeError(f"expected {a.max_len} decode steps, got {toks.shape[1]}")
+        return all_gather_rows(toks, counts) if world > 1 else toks
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    lat = []
+    for i in range(a.steps):
+        s0 = time.perf_counter()
+        out = step(i)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - s0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert out.shape == (a.batch * world, a.max_len)
+
+    result = None
+    if rank == 0:
+        lat.sort()
+        N = dims.n_tokens(a.height, a.width)
+        esz = 2 if a.dtype == "bf16" else 4
+        result = {
+            "metric": "images/sec (OCRModel.generate, greedy, max_len=256, 224x672 px)",
+            "value": round(a.batch * world * a.steps / elapsed, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1000 * elapsed / a.steps, 3),
+            "p50_latency_ms": round(1000 * lat[len(lat) // 2], 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic U[0,1) images, deterministic random-init weights (texocr_amd.synth seed 0)",
+            "config": {"workload": f"BASELINE configs[1]: config.yml dims (256-d/8h/4L enc + 4L dec, patch 16, PatchEmbedding C=3), "
+                                   f"batch {a.batch}/GPU, {a.height}x{a.width}, greedy max_len={a.max_len}",
+                       "global_batch": a.batch * world, "tokens_per_image": N, "parallelism": f"dp{world} (images sharded, "
+                       "all-gather of token ids)"},
+        }
+        if not a.no_roofline:
+            eng.profile(True)
+            model.generate(imgs[0], a.max_len)
+            torch.cuda.synchronize()
+            ms, n = eng.profile_read(0)
+            ems, en = eng.profile_read(1)
+            sms, sn = eng.profile_read(2)
+            eng.profile(False)
+            algo = a.batch * dims.dec_heads * 2 * N * 64 * esz
+            ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
+                                  "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                                  "traffic": None, "algorithmic_bytes_per_launch": algo,
+                                  "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
+                                  "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1)}
+        if not a.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(dims, sd_np, a)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

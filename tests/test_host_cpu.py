@@ -1,0 +1,120 @@
+"""Host-side logic that needs no GPU: config mapping, the synthetic-weight recipe, the data-parallel
+sharding helpers (incl. a 2-process gloo run of the all-gather + global-eos trim)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from texocr_amd import synth
+from texocr_amd.config import Dims, default_config
+from texocr_amd.dist import all_gather_rows, global_eos_steps, shard_bounds, sharded_generate
+
+
+def test_dims_from_reference_config():
+    d = Dims.from_config(default_config())
+    assert (d.embed_dim, d.enc_heads, d.enc_layers, d.dec_layers, d.vocab, d.max_len) == (256, 8, 4, 4, 1000, 256)
+    assert (d.bos, d.eos, d.pad) == (998, 997, 999)
+    assert d.enc_inner == 512 and d.enc_ffn == 1024 and d.n_tokens(224, 672) == 589 and d.n_pos == 1 + 42 * 42
+    cfg = default_config()
+    del cfg["max_length"]
+    with pytest.raises(ValueError, match="max_length"):
+        Dims.from_config(cfg)
+    with pytest.raises(ValueError, match="embed_dim must match"):
+        Dims.from_config(default_config(encoder={"embed_dim": 768}))
+    with pytest.raises(ValueError):
+        Dims(canvas=224).check_image(3, 224, 230)
+    with pytest.raises(ValueError):
+        Dims(canvas=224).check_image(3, 224, 448)
+    with pytest.raises(ValueError):
+        Dims(canvas=224).check_image(1, 224, 224)
+
+
+def test_synth_is_deterministic_and_param_count():
+    d = Dims(canvas=672)
+    a, b = synth.synth_state_dict(d, 0), synth.synth_state_dict(d, 0)
+    assert len(a) == 144                                   # default config has 144 state_dict keys
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    uniq = {id(v): v for v in a.values()}
+    assert sum(v.size for v in uniq.values()) == 15_409_896   # north-star shape, unique params
+    assert sum(v.size for v in a.values()) == 15_419_112       # state_dict elements incl. aliased LN keys
+    c = synth.synth_state_dict(d, 1)
+    assert not np.array_equal(a["decoder.net.to_logits.weight"], c["decoder.net.to_logits.weight"])
+    img = synth.synth_images(2, 3, 32, 48, 11)
+    assert img.dtype == np.float32 and img.min() >= 0 and img.max() < 1
+
+
+def test_shard_bounds_cover():
+    for total in (1, 7, 64, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _ref_break(tokens, eos, bos):
+    """decoder.py:97-116 restated as a loop over an already decoded token matrix."""
+    out = torch.full((tokens.shape[0], 1), bos, dtype=torch.long)
+    for i in range(tokens.shape[1]):
+        out = torch.cat([out, tokens[:, i:i + 1]], 1)
+        if eos is not None and (out == eos).any(dim=1).all():
+            break
+    return out.shape[1] - 1
+
+
+def test_global_eos_steps_matches_reference_loop():
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        B, T = int(torch.randint(1, 5, (1,), generator=g)), int(torch.randint(1, 12, (1,), generator=g))
+        toks = torch.randint(0, 4, (B, T), generator=g)
+        for eos, bos in ((2, 3), (3, 3), (None, 3), (7, 3)):
+            assert global_eos_steps(toks, eos, bos) == _ref_break(toks, eos, bos), (toks, eos, bos)
+
+
+def _fake_generate(img, max_len):
+    # deterministic per-image "decode": depends only on that image -> rows are independent like the real path
+    base = (img.reshape(img.shape[0], -1).sum(1) * 1000).long()
+    return (base[:, None] + torch.arange(max_len)[None, :] * 7) % 13
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        imgs = torch.from_numpy(synth.synth_images(total, 1, 4, 4, seed=3))
+        out = sharded_generate(_fake_generate, imgs, 10, eos=5, bos=12)
+        lo, hi = shard_bounds(total, rank, world)
+        out2 = sharded_generate(_fake_generate, imgs[lo:hi], 10, eos=5, bos=12, images_are_local=True, global_batch=total)
+        rows = all_gather_rows(torch.full((hi - lo, 2), rank), [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]
+                                                               for r in range(world)])
+        q.put((rank, out.numpy(), out2.numpy(), rows.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [6, 5])
+def test_sharded_generate_gloo_world2(total):
+    world, port = 2, 29500 + (os.getpid() % 2000) + total
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    imgs = torch.from_numpy(synth.synth_images(total, 1, 4, 4, seed=3))
+    full = _fake_generate(imgs, 10)
+    want = full[:, :global_eos_steps(full, 5, 12)].numpy()
+    for rank, out, out2, rows in res:
+        assert np.array_equal(out, want) and np.array_equal(out2, want)
+        exp_rows = np.concatenate([np.full((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0], 2), r)
+                                   for r in range(world)])
+        assert np.array_equal(rows, exp_rows)

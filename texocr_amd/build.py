@@ -1,0 +1,38 @@
+"""Builds the in-tree HIP library (texocr_amd/libtexocr_hip.so) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree to the GPU box."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libtexocr_hip.so")
+SOURCES = ["engine.hip"]
+HEADERS = ["common.h", "gemm_big.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "step.h"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "texocr.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result",
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    if verbose:
+        print("[texocr_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

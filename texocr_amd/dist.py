@@ -1,0 +1,89 @@
+"""Multi-GPU sharding of OCRModel.generate(): one process per GPU, images sharded across ranks, ONE
+collective at the end (all-gather of the generated token ids; optionally of the logits).
+
+The reference has no multi-device code.  The path shards naturally: every image's
+encode + decode is independent of every other image except for the GLOBAL eos break of
+AutoRegressiveDecoder.generate (reference model/decoder.py:115-116).  To keep that break exact without a
+per-step collective, every rank decodes its shard to ``max_len`` with the eos check disabled, the token
+blocks are all-gathered (RCCL over xGMI on GPUs: backend "nccl"; gloo on CPU in the tests), and the global
+break is applied afterwards by trimming at the first step where every row of the GLOBAL batch contains eos
+(rows never interact, so the trimmed result equals the single-device result).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of `total` rows for `rank`; sizes differ by at most one row."""
+    if not 0 <= rank < world:
+        raise ValueError("rank outside world")
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_eos_steps(tokens: torch.Tensor, eos: Optional[int], bos: Optional[int] = None) -> int:
+    """Number of columns the reference would return for this GLOBAL batch: it stops after the first step
+    at which every row contains eos (the BOS column counts too, decoder.py:115)."""
+    B, T = tokens.shape
+    if eos is None or T == 0:
+        return T
+    seen = (tokens == eos).cumsum(dim=1) > 0
+    if bos is not None and bos == eos:
+        seen = torch.ones_like(seen)
+    all_seen = seen.all(dim=0)
+    idx = torch.nonzero(all_seen)
+    return int(idx[0].item()) + 1 if idx.numel() else T
+
+
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
+    """All-gather row blocks of possibly different heights (pads to the tallest, one collective)."""
+    world = len(counts)
+    if world == 1:
+        return local
+    tall = max(counts)
+    if local.shape[0] < tall:
+        pad = torch.zeros((tall - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad], dim=0)
+    local = local.contiguous()
+    out = torch.empty((world * tall,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    if all(c == tall for c in counts):
+        return out
+    return torch.cat([out[r * tall: r * tall + c] for r, c in enumerate(counts)], dim=0)
+
+
+def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images: torch.Tensor, max_len: int,
+                     eos: Optional[int], bos: Optional[int] = None, group=None,
+                     images_are_local: bool = False, global_batch: Optional[int] = None) -> torch.Tensor:
+    """Data-parallel generate.
+
+    generate_local(img_shard, max_len) -> (b_local, max_len) int64 tokens decoded WITHOUT the eos break
+    (e.g. ``lambda x, n: model._engine.generate(x, n, eos=None)``).
+    `images` is either the global batch (every rank holds it; the rank's shard is sliced out) or, with
+    images_are_local=True, already this rank's shard (then `global_batch` gives the total row count).
+    Returns the GLOBAL (B, n_steps) token tensor on every rank."""
+    if not dist.is_initialized():
+        toks = generate_local(images, max_len)
+        return toks[:, :global_eos_steps(toks, eos, bos)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if images_are_local:
+        total = global_batch if global_batch is not None else images.shape[0] * world
+        local = images
+    else:
+        total = images.shape[0]
+        lo, hi = shard_bounds(total, rank, world)
+        local = images[lo:hi]
+    counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    if local.shape[0] != counts[rank]:
+        raise ValueError(f"rank {rank} holds {local.shape[0]} images, expected {counts[rank]}")
+    toks = generate_local(local, max_len) if local.shape[0] else torch.empty((0, max_len), dtype=torch.int64,
+                                                                              device=images.device)
+    if toks.shape[1] != max_len:
+        raise ValueError("generate_local must decode exactly max_len steps (eos break disabled)")
+    full = all_gather_rows(toks, counts, group)
+    return full[:, :global_eos_steps(full, eos, bos)]
