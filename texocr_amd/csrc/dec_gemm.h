@@ -13,13 +13,15 @@
 //   EPI_BIAS_RES: y = acc + b + residual                   (attention.py:66, :35-38)
 //   EPI_LOGITS: logits = acc + b                           (decoder.py:60, last position only)
 //
-// gfx950 mapping: block = 4 waves, output tile = (16*MT rows) x 32 columns; the four waves split K in
-// interleaved 64-byte chunks (each streams a distinct quarter of the weight rows straight from L2 into
-// VGPRs -- weights are read once per block, no LDS round trip), partial tiles are summed through LDS and the
-// epilogue runs on the reduced tile.  The normalised A rows (K = embed_dim) live in LDS, XOR-swizzled for
-// conflict-free ds_read_b128 fragment reads.  The decode position t is read from device memory so that one
+// These launches are latency chains, not throughput kernels (a few MFLOP each), so the structure minimises
+// dependent memory round trips: output tile = 16 rows x 32 columns per 256-thread block (many small blocks
+// -> every block's weight slice is 32 rows x K, read once, straight from L2/MALL into VGPRs); the four
+// waves split K in interleaved 64-byte chunks and each wave issues ALL of its weight/activation fragment
+// loads before the first MFMA; the LayerNorm prologue handles its 16 rows in one pass (16 lanes per row,
+// gamma/beta/bias/residual prefetched at kernel entry); partial tiles are summed through LDS and the
+// epilogue is spread over all 256 threads.  The decode position t is read from device memory so that one
 // captured launch sequence can be replayed for every step.
-// Bound: latency / L2 weight streaming (M <= 64 per tile; the arithmetic is a few microseconds at most).
+// Bound: latency / L2 weight streaming.
 #pragma once
 #include "common.h"
 
@@ -49,8 +51,11 @@ template <typename T> struct DecGemmArgs {
     float* logits;                  // [rows][N]
 };
 
+constexpr int DG_BM = 16, DG_BN = 32, DG_GROUP = 8;   // DG_GROUP: k-chunks a wave keeps in flight at once
+
+// LN over a row spread across 16 lanes, NVMAX float4 per lane (row length 64*nv), gamma/beta in registers
 template <int NVMAX>
-__device__ inline void ln16(float4 (&v)[NVMAX], int nv, const float* gamma, const float* beta, int sub, float inv_d) {
+__device__ inline void ln16(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX], const float4 (&b)[NVMAX], float inv_d) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) if (i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -64,10 +69,8 @@ __device__ inline void ln16(float4 (&v)[NVMAX], int nv, const float* gamma, cons
     const float rstd = 1.0f / sqrtf(row16_sum(q) * inv_d + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) if (i < nv) {
-        const float4 g = *reinterpret_cast<const float4*>(gamma + i * 64 + sub * 4);
-        const float4 b = *reinterpret_cast<const float4*>(beta + i * 64 + sub * 4);
-        v[i].x = v[i].x * rstd * g.x + b.x; v[i].y = v[i].y * rstd * g.y + b.y;
-        v[i].z = v[i].z * rstd * g.z + b.z; v[i].w = v[i].w * rstd * g.w + b.w;
+        v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
+        v[i].z = v[i].z * rstd * g[i].z + b[i].z; v[i].w = v[i].w * rstd * g[i].w + b[i].w;
     }
 }
 
@@ -78,141 +81,165 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
     return r * row_bytes + ((piece ^ (r & pmask)) << 4) + ((k * (int)sizeof(T)) & 15);
 }
 
-template <typename T, int MT, int PRO, int EPI, int NVMAX>
+template <typename T, int PRO, int EPI, int NVMAX>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK, BM = 16 * MT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave id must be PROVABLY wave-uniform: MFMA ignores EXEC, so a guard the compiler lowers to EXEC
+    // masking (instead of a scalar branch) would still execute the MFMA on stale registers
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * 32;
+    const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * DG_BN;
     const int K = a.K, rows = a.rows;
     const int row_bytes = K * (int)sizeof(T);
     const int pmask = min(16, row_bytes >> 4) - 1;
+
+    // ---- epilogue operands: thread -> (row reg = wave, C/D lane = lane); fetched now, used at the end ----
+    const int em = m0 + lg * 4 + wave;                        // output row of this thread
+    const int emc = min(em, rows - 1);
+    const int na = n0 + lr, nb = n0 + 16 + lr;                // the two 16-column tiles
+    float e_b0 = 0.f, e_b1 = 0.f, e_res0 = 0.f, e_res1 = 0.f;
+    if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
+        e_b0 = a.bias[na]; e_b1 = a.bias[nb];
+        if constexpr (EPI == EPI_GLU_RES) e_res0 = a.resid[(size_t)emc * a.D + (n0 >> 1) + lr];
+    } else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_LOGITS) {
+        e_b0 = a.bias[min(na, a.N - 1)]; e_b1 = a.bias[min(nb, a.N - 1)];
+        if constexpr (EPI == EPI_BIAS_RES) { e_res0 = a.resid[(size_t)emc * a.D + na]; e_res1 = a.resid[(size_t)emc * a.D + nb]; }
+    }
     int t = 0;
     if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = *a.t_ptr;
 
-    // ------------------------------ prologue: normalised rows -> LDS ------------------------------
+    // ---- weight fragments of the first group: issued before the prologue so they fly under it ----
+    const int nch = K / KCH;                                  // 64-byte k-chunks per row
+    const int my_nch = (nch - wave + 3) >> 2;                 // chunks wave, wave+4, ...
+    const int wr0 = min(na, a.N - 1), wr1 = min(nb, a.N - 1);
+    const T* w0 = a.W + (size_t)wr0 * K + lg * PER16;
+    const T* w1 = a.W + (size_t)wr1 * K + lg * PER16;
+    u32x4 fw0[DG_GROUP], fw1[DG_GROUP], fa[DG_GROUP];
+    auto load_w = [&](int g0) {
+#pragma unroll
+        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) {
+            const int kc = wave + 4 * (g0 + c);
+            fw0[c] = ld16(w0 + kc * KCH); fw1[c] = ld16(w1 + kc * KCH);
+        }
+    };
+    auto load_a_global = [&](int g0) {
+        const int m = min(m0 + lr, rows - 1);
+#pragma unroll
+        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch)
+            fa[c] = ld16(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+    };
+    load_w(0);
+    if constexpr (PRO == PRO_NONE) load_a_global(0);
+
+    // ------------------------------ prologue: 16 normalised rows -> LDS ------------------------------
     if constexpr (PRO != PRO_NONE) {
-        const int sub = tid & 15, nv = K >> 6;
+        const int sub = tid & 15, r = tid >> 4, nv = K >> 6;
         const float inv_d = 1.0f / K;
-        for (int r = tid >> 4; r < BM; r += 16) {
-            const int m = min(m0 + r, rows - 1);
-            float4 v[NVMAX];
-            if constexpr (PRO == PRO_EMBED) {
-                const float* te = a.tok_emb + (size_t)a.tok[m] * K;
-                const float* pe = a.pos_emb + (size_t)t * K;
+        const int m = min(m0 + r, rows - 1);
+        float4 v[NVMAX], g[NVMAX], b[NVMAX];
 #pragma unroll
-                for (int i = 0; i < NVMAX; ++i) if (i < nv) {
-                    const float4 p = *reinterpret_cast<const float4*>(te + i * 64 + sub * 4);
-                    const float4 q = *reinterpret_cast<const float4*>(pe + i * 64 + sub * 4);
-                    v[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < NVMAX; ++i) if (i < nv)
-                    v[i] = *reinterpret_cast<const float4*>(a.y + (size_t)m * K + i * 64 + sub * 4);
-            }
-            if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, a.gamma, a.beta, sub, inv_d);
-            if constexpr (PRO == PRO_EMBED || PRO == PRO_LN2) {
-                if (blockIdx.x == 0 && m0 + r < rows) {
-#pragma unroll
-                    for (int i = 0; i < NVMAX; ++i) if (i < nv)
-                        *reinterpret_cast<float4*>(a.x_out + (size_t)m * K + i * 64 + sub * 4) = v[i];
-                }
-            }
-            ln16<NVMAX>(v, nv, a.gamma, a.beta, sub, inv_d);
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+            g[i] = *reinterpret_cast<const float4*>(a.gamma + i * 64 + sub * 4);
+            b[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
+        }
+        if constexpr (PRO == PRO_EMBED) {
+            const float* te = a.tok_emb + (size_t)a.tok[m] * K;
+            const float* pe = a.pos_emb + (size_t)t * K;
 #pragma unroll
             for (int i = 0; i < NVMAX; ++i) if (i < nv) {
-                unsigned char* dst = smem + a_off<T>(r, i * 64 + sub * 4, row_bytes, pmask);
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(dst) = v[i];
-                } else {
-                    union { bf16 h[4]; uint2 u; } c;
-                    c.h[0] = __float2bfloat16(v[i].x); c.h[1] = __float2bfloat16(v[i].y);
-                    c.h[2] = __float2bfloat16(v[i].z); c.h[3] = __float2bfloat16(v[i].w);
-                    *reinterpret_cast<uint2*>(dst) = c.u;
-                }
+                const float4 p = *reinterpret_cast<const float4*>(te + i * 64 + sub * 4);
+                const float4 q = *reinterpret_cast<const float4*>(pe + i * 64 + sub * 4);
+                v[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVMAX; ++i) if (i < nv)
+                v[i] = *reinterpret_cast<const float4*>(a.y + (size_t)m * K + i * 64 + sub * 4);
+        }
+        if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, g, b, inv_d);
+        if constexpr (PRO == PRO_EMBED || PRO == PRO_LN2) {
+            if (blockIdx.x == 0 && m0 + r < rows) {
+#pragma unroll
+                for (int i = 0; i < NVMAX; ++i) if (i < nv)
+                    *reinterpret_cast<float4*>(a.x_out + (size_t)m * K + i * 64 + sub * 4) = v[i];
+            }
+        }
+        ln16<NVMAX>(v, nv, g, b, inv_d);
+#pragma unroll
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+            unsigned char* dst = smem + a_off<T>(r, i * 64 + sub * 4, row_bytes, pmask);
+            if constexpr (sizeof(T) == 4) {
+                *reinterpret_cast<float4*>(dst) = v[i];
+            } else {
+                union { bf16 h[4]; uint2 u; } c;
+                c.h[0] = __float2bfloat16(v[i].x); c.h[1] = __float2bfloat16(v[i].y);
+                c.h[2] = __float2bfloat16(v[i].z); c.h[3] = __float2bfloat16(v[i].w);
+                *reinterpret_cast<uint2*>(dst) = c.u;
             }
         }
         __syncthreads();
     }
 
     // ------------------------------ main: wave w owns k-chunks w, w+4, ... ------------------------------
-    f32x4 acc[MT][2];
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int g0 = 0; g0 < my_nch; g0 += DG_GROUP) {
+        if (g0 > 0) { load_w(g0); if constexpr (PRO == PRO_NONE) load_a_global(g0); }
+        if constexpr (PRO != PRO_NONE) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = acc[i][0]; }
-    const int nch = K / KCH;
-    const int wr0 = min(n0 + lr, a.N - 1), wr1 = min(n0 + 16 + lr, a.N - 1);
-    const T* w0 = a.W + (size_t)wr0 * K + lg * PER16;
-    const T* w1 = a.W + (size_t)wr1 * K + lg * PER16;
-    for (int kc = wave; kc < nch; kc += 4) {
-        const u32x4 fw0 = ld16(w0 + kc * KCH), fw1 = ld16(w1 + kc * KCH);
-        u32x4 fa[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            if constexpr (PRO != PRO_NONE) {
-                fa[i] = ld16(smem + a_off<T>(16 * i + lr, kc * KCH + lg * PER16, row_bytes, pmask));
-            } else {
-                const int m = min(m0 + 16 * i + lr, rows - 1);
-                fa[i] = ld16(a.A + (size_t)m * K + kc * KCH + lg * PER16);
-            }
+            for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch)
+                fa[c] = ld16(smem + a_off<T>(lr, (wave + 4 * (g0 + c)) * KCH + lg * PER16, row_bytes, pmask));
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) { mma16<T>(acc[i][0], fa[i], fw0); mma16<T>(acc[i][1], fa[i], fw1); }
+        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) { mma16<T>(acc0, fa[c], fw0[c]); mma16<T>(acc1, fa[c], fw1[c]); }
     }
 
     // ------------------------------ cross-wave K reduction through LDS ------------------------------
-    __syncthreads();                                  // everyone is done reading the A image
-    f32x4* red = reinterpret_cast<f32x4*>(smem);      // [wave][MT][2][64]
+    __syncthreads();                                          // everyone is done reading the A image
+    float* red = reinterpret_cast<float*>(smem);              // [wave][half][reg][lane]
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { red[((wave * MT + i) * 2 + 0) * 64 + lane] = acc[i][0];
-                                   red[((wave * MT + i) * 2 + 1) * 64 + lane] = acc[i][1]; }
+    for (int r = 0; r < 4; ++r) { red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
+                                  red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r]; }
     __syncthreads();
-    if (wave >= MT) return;
-    const int mi = wave;
-    f32x4 c0 = red[((0 * MT + mi) * 2 + 0) * 64 + lane], c1 = red[((0 * MT + mi) * 2 + 1) * 64 + lane];
+    // thread (wave, lane) finalises C/D register r = wave of lane `lane`: row = 4*(lane>>4) + wave, col = lane&15
+    float c0 = 0.f, c1 = 0.f;
 #pragma unroll
-    for (int w = 1; w < 4; ++w) { c0 += red[((w * MT + mi) * 2 + 0) * 64 + lane];
-                                  c1 += red[((w * MT + mi) * 2 + 1) * 64 + lane]; }
+    for (int w = 0; w < 4; ++w) { c0 += red[((w * 2 + 0) * 4 + wave) * 64 + lane]; c1 += red[((w * 2 + 1) * 4 + wave) * 64 + lane]; }
 
-    // ------------------------------ epilogue (C/D layout: col = lane&15, row = 4*(lane>>4)+reg) ------------------------------
+    // ------------------------------ epilogue ------------------------------
+    if (em >= rows) return;
+    if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
+        const int j = (n0 >> 1) + lr;                         // 32 interleaved weight rows -> 16 outputs
+        const float v = c0 + e_b0, g = c1 + e_b1;
+        if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = v * sigmoidf(g) + e_res0;
+        else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(v * gelu_erf(g));
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * mi + lg * 4 + r;
-        if (m >= rows) continue;
-        const int na = n0 + lr, nb = n0 + 16 + lr;
-        if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
-            const int j = (n0 >> 1) + lr;             // 32 interleaved weight rows -> 16 outputs
-            const float v = c0[r] + a.bias[na], g = c1[r] + a.bias[nb];
-            if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)m * a.D + j] = v * sigmoidf(g) + a.resid[(size_t)m * a.D + j];
-            else a.h_out[(size_t)m * a.F + j] = Elem<T>::from_f32(v * gelu_erf(g));
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int n = h ? nb : na;
-                const float v = h ? c1[r] : c0[r];
-                if (n >= a.N) continue;
-                if constexpr (EPI == EPI_QKV || EPI == EPI_Q) {
-                    const int which = n / a.inner, f = n - which * a.inner;
-                    if (which == 0) a.q_out[(size_t)m * a.inner + f] = v;
-                    else {
-                        T* cache = (which == 1) ? a.k_cache : a.v_cache;
-                        cache[(((size_t)m * a.heads + (f >> 6)) * a.tmax + t) * DH + (f & 63)] = Elem<T>::from_f32(v);
-                    }
-                } else if constexpr (EPI == EPI_BIAS_RES) {
-                    a.y_out[(size_t)m * a.D + n] = v + a.bias[n] + a.resid[(size_t)m * a.D + n];
-                } else {   // EPI_LOGITS
-                    a.logits[(size_t)m * a.N + n] = v + a.bias[n];
+        for (int h = 0; h < 2; ++h) {
+            const int n = h ? nb : na;
+            const float v = h ? c1 : c0;
+            if (n >= a.N) continue;
+            if constexpr (EPI == EPI_QKV || EPI == EPI_Q) {
+                const int which = n / a.inner, f = n - which * a.inner;
+                if (which == 0) a.q_out[(size_t)em * a.inner + f] = v;
+                else {
+                    T* cache = (which == 1) ? a.k_cache : a.v_cache;
+                    cache[(((size_t)em * a.heads + (f >> 6)) * a.tmax + t) * DH + (f & 63)] = Elem<T>::from_f32(v);
                 }
+            } else if constexpr (EPI == EPI_BIAS_RES) {
+                a.y_out[(size_t)em * a.D + n] = v + (h ? e_b1 : e_b0) + (h ? e_res1 : e_res0);
+            } else {   // EPI_LOGITS
+                a.logits[(size_t)em * a.N + n] = v + (h ? e_b1 : e_b0);
             }
         }
     }
 }
 
-template <typename T, int MT>
+template <typename T>
 inline size_t dec_gemm_lds_bytes(int K, bool has_pro) {
-    const size_t red = (size_t)4 * MT * 2 * 64 * 16;
-    const size_t img = has_pro ? (size_t)16 * MT * K * sizeof(T) : 0;
+    const size_t red = (size_t)4 * 2 * 4 * 64 * 4;
+    const size_t img = has_pro ? (size_t)DG_BM * K * sizeof(T) : 0;
     return red > img ? red : img;
 }
 

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -31,6 +32,14 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
         if (_e != hipSuccess)                                                                           \
             return fail(TXO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));                  \
     } while (0)
+
+static const bool g_dbg = getenv("TXO_DEBUG_SYNC") != nullptr;
+static void dbg(hipStream_t s, const char* what, int l = -1) {
+    if (!g_dbg) return;
+    hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "[txo] %s %d -> %s\n", what, l, hipGetErrorString(e));
+    fflush(stderr);
+}
 
 struct HostTensor { std::vector<int64_t> shape; std::vector<float> data; };
 
@@ -342,22 +351,10 @@ struct Engine : EngineBase {
     template <int PRO, int EPI>
     int launch_dec_gemm(hipStream_t s, DecGemmArgs<T> a) {
         const bool has_pro = PRO != PRO_NONE;
-        int MT = a.rows <= 16 ? 1 : (a.rows <= 32 ? 2 : 4);
-        while (has_pro && MT > 1 && (size_t)16 * MT * a.K * sizeof(T) > 128 * 1024) MT >>= 1;
-        const dim3 grid((a.N + 31) / 32, (a.rows + 16 * MT - 1) / (16 * MT)), blk(256);
-        const bool big = has_pro && a.K > 256;
-#define TXO_DG(MTV, NVV)                                                                              \
-        do {                                                                                          \
-            auto kern = dec_gemm_kernel<T, MTV, PRO, EPI, NVV>;                                       \
-            const size_t lds = dec_gemm_lds_bytes<T, MTV>(a.K, has_pro);                              \
-            if (lds > 64 * 1024)                                                                      \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
-            hipLaunchKernelGGL(kern, grid, blk, lds, s, a);                                           \
-        } while (0)
-        if (big) { if (MT == 1) TXO_DG(1, 12); else if (MT == 2) TXO_DG(2, 12); else TXO_DG(4, 12); }
-        else     { if (MT == 1) TXO_DG(1, 4);  else if (MT == 2) TXO_DG(2, 4);  else TXO_DG(4, 4); }
-#undef TXO_DG
+        const dim3 grid((a.N + DG_BN - 1) / DG_BN, (a.rows + DG_BM - 1) / DG_BM), blk(256);
+        const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
+        if (has_pro && a.K > 256) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12>), grid, blk, lds, s, a);
+        else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4>), grid, blk, lds, s, a);
         return 0;
     }
 
@@ -386,15 +383,20 @@ struct Engine : EngineBase {
                 DecGemmArgs<T> a = base; a.N = 3 * Id; a.K = D; a.W = dec_self[l].wqkv; a.y = dy; a.x_out = dx;
                 a.k_cache = kc; a.v_cache = vc;
                 if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_QKV>(s, a) : launch_dec_gemm<PRO_LN2, EPI_QKV>(s, a))) return r;
+                dbg(s, "self qkv", l);
                 launch_dec_attn(s, kc, vc, Tmax, -1, false);
+                dbg(s, "self attn", l);
                 DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = dao;
                 o.resid = dx; o.y_out = dy;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+                dbg(s, "self out", l);
             }
             {   // cross attention over the cached encoder projections
                 DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy; a.x_out = dx;
                 if (int r = launch_dec_gemm<PRO_LN2, EPI_Q>(s, a)) return r;
+                dbg(s, "cross q", l);
                 launch_dec_attn(s, ckv + (size_t)(2 * l) * cross_stride, ckv + (size_t)(2 * l + 1) * cross_stride, N, N, true);
+                dbg(s, "cross attn", l);
                 DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = dao;
                 o.resid = dx; o.y_out = dy;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
@@ -402,7 +404,9 @@ struct Engine : EngineBase {
             {   // GeGLU feed-forward
                 DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = dy; a.x_out = dx;
                 a.h_out = dhid; a.F = Fd;
+                dbg(s, "cross out", l);
                 if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
+                dbg(s, "ffn1", l);
                 DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = dhid;
                 o.resid = dx; o.y_out = dy;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, o)) return r;
@@ -410,9 +414,12 @@ struct Engine : EngineBase {
         }
         DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.y = dy; f.gamma = decn_g; f.beta = decn_b;
         f.logits = dlogits;
+        dbg(s, "ffn2 (last)");
         if (int r = launch_dec_gemm<PRO_LNF, EPI_LOGITS>(s, f)) return r;
+        dbg(s, "logits");
         StepArgs sa{dlogits, V, B, cur_tok, tokens_out, out_stride, logits_out, st, eos_seen, done_flag, eos};
         hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
+        dbg(s, "argmax");
         if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
         return 0;
     }

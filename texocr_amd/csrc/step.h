@@ -35,10 +35,34 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(StepArgs a) {
     const int t = a.st->t;
     const float* lg = a.logits + (size_t)row * a.V;
     float best = -3.4e38f; int bi = 0x7fffffff;
-    for (int j = lane; j < a.V; j += 64) {
-        const float v = lg[j];
-        if (a.logits_out) a.logits_out[((size_t)row * a.out_stride + t) * a.V + j] = v;
-        if (v > best) { best = v; bi = j; }       // ascending j: first maximum wins inside a lane
+    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
+    if ((a.V & 3) == 0) {                      // rows are 16-byte aligned: four float4 per lane in flight
+        const int n4 = a.V >> 2;
+        for (int base = 0; base < n4; base += 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j4 = base + u * 64 + lane;
+                v[u] = j4 < n4 ? reinterpret_cast<const float4*>(lg)[j4] : make_float4(-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j4 = base + u * 64 + lane;
+                if (j4 >= n4) continue;
+                if (lo) reinterpret_cast<float4*>(lo)[j4] = v[u];
+                const int j = j4 * 4;                          // ascending index: first maximum wins inside a lane
+                if (v[u].x > best) { best = v[u].x; bi = j; }
+                if (v[u].y > best) { best = v[u].y; bi = j + 1; }
+                if (v[u].z > best) { best = v[u].z; bi = j + 2; }
+                if (v[u].w > best) { best = v[u].w; bi = j + 3; }
+            }
+        }
+    } else {
+        for (int j = lane; j < a.V; j += 64) {
+            const float v = lg[j];
+            if (lo) lo[j] = v;
+            if (v > best) { best = v; bi = j; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
