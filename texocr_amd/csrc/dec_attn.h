@@ -1,33 +1,49 @@
-// Decode-step attention: ONE query row per (image, head) against a cached K/V panel.
+// Decode-step attention sub-layer front half: LayerNorm sandwich + q (cross) / q,k,v (self) projection +
+// ONE query row per (image, head) against the cached K/V panel, in one launch.
 //
-// Reference (KV-cached form of MultiHeadAttention.forward, model/attention.py:148-173):
-//   cross : keys/values = per-layer projections of the raw encoder output, N = h*w+1 rows, non-causal.
-//           The reference re-projects them from `enc` at every step (:124-126); here they are projected
-//           once per generate() call and this kernel re-reads them every step -> the HBM-bound kernel of
-//           the whole path.
-//   self  : keys/values of positions 0..t (causal; with one query at the last position the triangular
-//           fill of :158-163 masks nothing that is cached).
-//   energy = q.k * 0.125 ; softmax (max-subtracted, fp32) ; out = sum_j p_j v_j ; heads merged
-//   'b h n d -> b n (h d)' on the way out.
+// Reference (KV-cached form of AttentionLayers.forward + MultiHeadAttention.forward, model/attention.py):
+//   x = LN(y) (next residual; or x = tok_emb + pos_emb for the first sub-layer, decoder.py:51-52)
+//   z = LN(x)                                            (:243, same shared gamma/beta)
+//   q = z Wq^T  [self: also k_t = z Wk^T, v_t = z Wv^T appended to the cache]   (:124-127, no bias)
+//   cross : keys/values = per-layer projections of the raw encoder output, N rows, non-causal.  The reference
+//           re-projects them from `enc` at every step (:124-126); here they are projected once per generate()
+//           and re-read every step -> the HBM-bound kernel of the whole path.
+//   self  : keys/values of positions 0..t (causal; with one query at the last position the triangular fill
+//           of :158-163 masks nothing that is cached).
+//   energy = q.k * 0.125 ; softmax (max-subtracted, fp32) ; out = sum_j p_j v_j ; 'b h n d -> b n (h d)'.
 //
-// Layout: K,V [images*heads][Lmax][64] of T (f32: 256-byte rows, bf16: 128-byte rows).
-// gfx950 mapping: one 256-thread block per (image, head).  Every wave-instruction reads 1 KiB of contiguous
-// K (or V) rows with 16 B per lane (LPR = 16 or 8 lanes per row), 8 such loads in flight per wave.  Scores go
-// to LDS, the block does one max/sum pass, then the V sweep accumulates 16-byte column pieces per lane and
-// reduces across lanes (shuffles) and waves (LDS).  Algorithmic bytes per launch = images*heads*2*L*64*sizeof(T).
-// Bound: HBM (8 TB/s peak).
+// Layout: K,V [images*heads][lmax][64] of T (f32: 256-byte rows, bf16: 128-byte rows).
+//
+// gfx950 mapping: one 256-thread block per (image, head).  The whole K and V panel of the block (up to
+// NL wave-instructions of 1 KiB per wave each) is requested AT KERNEL ENTRY, 16 B per lane, straight into
+// VGPRs: one HBM round trip for the launch instead of a load/compute ping-pong, ~300 KB in flight per CU.
+// While it flies, wave 0 normalises the image's row and all threads project the head's 64 (or 3x64)
+// outputs from L2-resident weights.  Scores stay in registers (each lane owns the keys it loaded); one
+// block-wide max and one sum/accumulator reduction go through LDS.  Longer panels (N > 32*NL keys in bf16,
+// 16*NL in f32) are processed in several passes with an online-softmax rescale.
+// Algorithmic bytes per launch = images*heads*2*len*64*sizeof(T).   Bound: HBM (8 TB/s peak).
 #pragma once
 #include "common.h"
 
 namespace txo {
 
+enum { ATT_CROSS = 0, ATT_SELF = 1 };
+enum { APRO_EMBED = 0, APRO_LN2 = 1 };
+
 template <typename T> struct DecAttnArgs {
-    const float* q;          // [images][heads*64] fp32
-    const T* K; const T* V;  // [images*heads][lmax][64]
-    T* out;                  // [images][heads*64]
+    // row prologue
+    const float* y;                 // [images][D] (APRO_LN2)
+    const int64_t* tok; const float* tok_emb; const float* pos_emb;   // APRO_EMBED
+    float* x_out;                   // [images][D] residual (written by the head-0 block)
+    const float* gamma; const float* beta;
+    int D;
+    const T* W;                     // cross: Wq [inner][D]; self: Wqkv [3*inner][D]
+    // attention
+    T* K; T* V;                     // [images*heads][lmax][64]; self mode appends row t
+    T* out;                         // [images][heads*64]
     int heads, lmax;
-    int len;                 // number of keys, or -1: read *t_ptr + 1 (self attention at position t)
-    const int* t_ptr;
+    int len;                        // cross: number of keys
+    const int* t_ptr;               // decode position (device)
 };
 
 template <typename T, int PER16>
@@ -43,99 +59,279 @@ __device__ inline void unpack16(const u32x4& raw, float (&f)[PER16]) {
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs<T> a) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];   // [len] scores, then [4][64] partial outputs + stats
+template <int NVMAX>
+__device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX], const float4 (&b)[NVMAX], float inv_d) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVMAX; ++i) if (i < nv) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+        v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
+        v[i].z = v[i].z * rstd * g[i].z + b[i].z; v[i].w = v[i].w * rstd * g[i].w + b[i].w;
+    }
+}
+
+// NL: wave-instructions (1 KiB each) of K (then of V) a wave keeps in registers per pass.
+// WB: projections whose weight rows are requested together at kernel entry (all of them when registers allow).
+// NARROW: embed_dim is not a multiple of 256 (test-size models): scalar row prologue.
+//
+// The hot loops are written WITHOUT data-dependent branches (clamped unconditional loads, masked scores of
+// -3e38 whose exp is exactly 0, selects): a guarded load becomes its own basic block and hipcc's waitcnt
+// insertion then falls back to vmcnt(0) per iteration, which serialises the whole K/V stream.
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW>
+__global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int LPR = DH / PER16;          // lanes per 64-element row: 16 (f32) / 8 (bf16)
     constexpr int KPI = 64 / LPR;            // keys per wave-instruction: 4 / 8
-    constexpr int UNR = 8;
+    constexpr int KPB = KPI * 4;             // keys per block-instruction (four waves)
+    constexpr int NP = MODE == ATT_SELF ? 3 : 1;
+    constexpr int NVMAX = 3;                 // row prologue: D <= 768 (one wave, float4 per lane per 256)
+    constexpr int WMAX = 8;                  // weight pieces per thread per projection per group (bf16: one group at D = 256)
     const int bh = blockIdx.x, img = bh / a.heads, head = bh - img * a.heads;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane % LPR, kq = lane / LPR;
-    const int L = a.len >= 0 ? a.len : (*a.t_ptr + 1);
-    const T* Kb = a.K + (size_t)bh * a.lmax * DH;
-    const T* Vb = a.V + (size_t)bh * a.lmax * DH;
+    const int D = a.D, inner = a.heads * DH;
+    T* Kb = a.K + (size_t)bh * a.lmax * DH;
+    T* Vb = a.V + (size_t)bh * a.lmax * DH;
+
+    __shared__ __attribute__((aligned(16))) float zs[768];   // normalised row
+    __shared__ __attribute__((aligned(16))) float qkv[3][DH];
     __shared__ float part[4][DH];
-    __shared__ float stat[8];
+    __shared__ float stat[12];
+
+    // ---- 0. projection weights: thread (d = tid>>2, prt = tid&3) owns 16-byte pieces prt, prt+4, ... of row d.
+    //         Requested first: they depend on nothing and are needed first. ----
+    const int pd = tid >> 2, prt = tid & 3;
+    const int pieces = (D * (int)sizeof(T)) >> 4;
+    const int ngrp = (pieces + 4 * WMAX - 1) / (4 * WMAX);   // weight groups per row (1 at D = 256)
+    u32x4 wreg[WB][WMAX];
+    auto issue_w = [&](int p0, int g) {
+#pragma unroll
+        for (int p = 0; p < WB; ++p) {
+            const int pp = min(p0 + p, NP - 1);
+            const T* wrow = a.W + ((size_t)pp * inner + head * DH + pd) * D;
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) wreg[p][i] = ld16(wrow + min(prt + 4 * (g * WMAX + i), pieces - 1) * PER16);
+        }
+    };
+    issue_w(0, 0);
+
+    // ---- 1. request the K panel of the first pass ----
+    int t = 0;
+    if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = *a.t_ptr;
+    const int L = MODE == ATT_CROSS ? a.len : t;             // cached keys (self: the new key t is handled apart)
+    const int Lm1 = max(L - 1, 0);
+    const int key0 = wave * KPI + kq;
+    u32x4 rk[NL], rv[NL];
+    auto issue_k = [&](int base) {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) rk[u] = ld16(Kb + (size_t)min(base + u * KPB + key0, Lm1) * DH + sub * PER16);
+    };
+    issue_k(0);
+
+    // ---- 2. row prologue (wave 0): x = LN(y) | emb ; z = LN(x) -> LDS ----
+    if (wave == 0) {
+        const float inv_d = 1.0f / D;
+        if constexpr (!NARROW) {
+            const int nv = D >> 8;
+            float4 v[NVMAX], g[NVMAX], b[NVMAX];
+#pragma unroll
+            for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+                const int c = i * 256 + lane * 4;
+                g[i] = *reinterpret_cast<const float4*>(a.gamma + c);
+                b[i] = *reinterpret_cast<const float4*>(a.beta + c);
+                if constexpr (APRO == APRO_EMBED) {
+                    const float4 p = *reinterpret_cast<const float4*>(a.tok_emb + (size_t)a.tok[img] * D + c);
+                    const float4 q = *reinterpret_cast<const float4*>(a.pos_emb + (size_t)t * D + c);
+                    v[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+                } else {
+                    v[i] = *reinterpret_cast<const float4*>(a.y + (size_t)img * D + c);
+                }
+            }
+            if constexpr (APRO == APRO_LN2) ln64<NVMAX>(v, nv, g, b, inv_d);
+            if (head == 0) {
+#pragma unroll
+                for (int i = 0; i < NVMAX; ++i) if (i < nv)
+                    *reinterpret_cast<float4*>(a.x_out + (size_t)img * D + i * 256 + lane * 4) = v[i];
+            }
+            ln64<NVMAX>(v, nv, g, b, inv_d);
+#pragma unroll
+            for (int i = 0; i < NVMAX; ++i) if (i < nv) *reinterpret_cast<float4*>(&zs[i * 256 + lane * 4]) = v[i];
+        } else {
+            const int ne = (D + 63) >> 6;
+            float vals[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) if (i < ne) {
+                const int c = i * 64 + lane;
+                vals[i] = 0.f;
+                if (c < D) {
+                    if constexpr (APRO == APRO_EMBED) vals[i] = a.tok_emb[(size_t)a.tok[img] * D + c] + a.pos_emb[(size_t)t * D + c];
+                    else vals[i] = a.y[(size_t)img * D + c];
+                }
+            }
+            auto ln_narrow = [&]() {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) if (i < ne) s += vals[i];
+                const float mean = wave_sum(s) * inv_d;
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) if (i < ne) { const float dl = (i * 64 + lane < D) ? vals[i] - mean : 0.f; q += dl * dl; }
+                const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) if (i < ne) {
+                    const int c = i * 64 + lane;
+                    vals[i] = c < D ? (vals[i] - mean) * rstd * a.gamma[c] + a.beta[c] : 0.f;
+                }
+            };
+            if constexpr (APRO == APRO_LN2) ln_narrow();
+            if (head == 0) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) if (i < ne) { const int c = i * 64 + lane; if (c < D) a.x_out[(size_t)img * D + c] = vals[i]; }
+            }
+            ln_narrow();
+#pragma unroll
+            for (int i = 0; i < 12; ++i) if (i < ne) { const int c = i * 64 + lane; if (c < D) zs[c] = vals[i]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. projection from the weight pieces already in flight ----
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += WB) {
+        float accp[WB];
+#pragma unroll
+        for (int p = 0; p < WB; ++p) accp[p] = 0.f;
+        for (int g = 0; g < ngrp; ++g) {
+            if (p0 > 0 || g > 0) issue_w(p0, g);
+#pragma unroll
+            for (int i = 0; i < WMAX; ++i) {
+                const int piece = prt + 4 * (g * WMAX + i);
+                const float keep = piece < pieces ? 1.f : 0.f;
+                const float* zp = &zs[min(piece, pieces - 1) * PER16];
+                float zf[PER16];
+#pragma unroll
+                for (int e = 0; e < PER16; ++e) zf[e] = zp[e] * keep;
+#pragma unroll
+                for (int p = 0; p < WB; ++p) {
+                    float wf[PER16];
+                    unpack16<T, PER16>(wreg[p][i], wf);
+#pragma unroll
+                    for (int e = 0; e < PER16; ++e) accp[p] = fmaf(wf[e], zf[e], accp[p]);
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < WB; ++p) if (p0 + p < NP) {
+            float v = accp[p];
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            if (prt == 0) qkv[p0 + p][pd] = v;
+        }
+    }
+    __syncthreads();
+    float s_new = 0.f;                                        // self: score of the new key t
+    if constexpr (MODE == ATT_SELF) {
+        // append k_t, v_t (rounded to the cache type, exactly what later steps will read back)
+        if (tid < 2 * DH) {
+            const int which = tid >> 6, dd = tid & 63;
+            const T val = Elem<T>::from_f32(qkv[1 + which][dd]);
+            (which ? Vb : Kb)[(size_t)t * DH + dd] = val;
+            qkv[1 + which][dd] = Elem<T>::to_f32(val);
+        }
+        __syncthreads();
+        s_new = wave_sum(qkv[0][lane] * ATTN_SCALE * qkv[1][lane]);
+    }
 
     // this lane's 16-byte piece of the query, pre-scaled (0.125 is exact)
     float qv[PER16];
 #pragma unroll
-    for (int e = 0; e < PER16; ++e) qv[e] = a.q[(size_t)img * a.heads * DH + head * DH + sub * PER16 + e] * ATTN_SCALE;
+    for (int e = 0; e < PER16; ++e) qv[e] = qkv[0][sub * PER16 + e] * ATTN_SCALE;
 
-    // ---- phase 1: scores ----
-    const int KPB = KPI * 4;                 // keys per block-iteration (all four waves)
-    for (int base = 0; base < L; base += KPB * UNR) {
-        u32x4 raw[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int key = min(base + u * KPB + wave * KPI + kq, L - 1);
-            raw[u] = ld16(Kb + (size_t)key * DH + sub * PER16);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            float kf[PER16];
-            unpack16<T, PER16>(raw[u], kf);
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            const int key = base + u * KPB + wave * KPI + kq;
-            if (sub == 0 && key < L) sc[key] = d;
-        }
-    }
-    __syncthreads();
-    // ---- phase 2: softmax statistics ----
-    float mx = -3.0e38f;
-    for (int j = tid; j < L; j += 256) mx = fmaxf(mx, sc[j]);
-    mx = wave_max(mx);
-    if (lane == 0) stat[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(stat[0], stat[1]), fmaxf(stat[2], stat[3]));
-    float sum = 0.f;
-    for (int j = tid; j < L; j += 256) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
-    sum = wave_sum(sum);
-    if (lane == 0) stat[4 + wave] = sum;
-    __syncthreads();
-    const float inv = 1.0f / ((stat[4] + stat[5]) + (stat[6] + stat[7]));
-
-    // ---- phase 3: out = sum_j p_j v_j ----
+    // ---- 4. passes over the panel (one pass when len <= NL*KPB) ----
+    float m_run = MODE == ATT_SELF ? s_new : -3.0e38f, l_run = 0.f;
     float acc[PER16];
 #pragma unroll
     for (int e = 0; e < PER16; ++e) acc[e] = 0.f;
-    for (int base = 0; base < L; base += KPB * UNR) {
-        u32x4 raw[UNR];
-        float pj[UNR];
+    const float count_me = sub == 0 ? 1.f : 0.f;              // each key's probability is summed once
+    auto do_pass = [&](int base, int slot) {
+        float sc[NL];
+        float mx = -3.0e38f;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int key = base + u * KPB + wave * KPI + kq;
-            const int kc = min(key, L - 1);
-            raw[u] = ld16(Vb + (size_t)kc * DH + sub * PER16);
-            pj[u] = key < L ? sc[kc] : 0.f;
+        for (int u = 0; u < NL; ++u) {
+            const int key = base + u * KPB + key0;
+            float kf[PER16];
+            unpack16<T, PER16>(rk[u], kf);
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
+            // the K registers of this slot are dead now: request the matching V rows into their place
+            rv[u] = ld16(Vb + (size_t)min(key, Lm1) * DH + sub * PER16);
+#pragma unroll
+            for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // butterfly: all LPR lanes get the dot
+            d = key < L ? d : -3.0e38f;
+            sc[u] = d;
+            mx = fmaxf(mx, d);
+            // keep the V requests in program order behind the K consumption (else both panels are live at once)
+            __builtin_amdgcn_sched_barrier(0);
         }
+        mx = wave_max(mx);
+        if (lane == 0) stat[slot * 4 + wave] = mx;
+        __syncthreads();
+        const float pm = fmaxf(fmaxf(stat[slot * 4 + 0], stat[slot * 4 + 1]), fmaxf(stat[slot * 4 + 2], stat[slot * 4 + 3]));
+        const float m_new = fmaxf(m_run, pm);
+        const float alpha = expf(m_run - m_new);              // first pass: exp(-huge) = 0 with acc = l = 0
+        m_run = m_new;
+        l_run *= alpha;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
+        for (int e = 0; e < PER16; ++e) acc[e] *= alpha;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const float p = expf(sc[u] - m_new);              // masked keys: exp(-3e38 - m) == 0 exactly
+            l_run = fmaf(p, count_me, l_run);
             float vf[PER16];
-            unpack16<T, PER16>(raw[u], vf);
+            unpack16<T, PER16>(rv[u], vf);
 #pragma unroll
-            for (int e = 0; e < PER16; ++e) acc[e] = fmaf(pj[u], vf[e], acc[e]);
+            for (int e = 0; e < PER16; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
         }
+    };
+    do_pass(0, 0);
+    for (int base = NL * KPB, slot = 1; base < L; base += NL * KPB, slot ^= 1) {   // long panels only
+        issue_k(base);
+        do_pass(base, slot);
     }
+
+    // ---- 5. reduce over key groups (shuffles), waves (LDS), normalise, merge heads ----
 #pragma unroll
     for (int e = 0; e < PER16; ++e) {
 #pragma unroll
         for (int o = 32; o >= LPR; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
     }
+    l_run = wave_sum(l_run);
     if (kq == 0) {
 #pragma unroll
         for (int e = 0; e < PER16; ++e) part[wave][sub * PER16 + e] = acc[e];
     }
+    if (lane == 0) stat[8 + wave] = l_run;
     __syncthreads();
     if (tid < DH) {
-        const float o = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) * inv;
-        a.out[(size_t)img * a.heads * DH + head * DH + tid] = Elem<T>::from_f32(o);
+        float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        float l = (stat[8] + stat[9]) + (stat[10] + stat[11]);
+        if constexpr (MODE == ATT_SELF) {
+            const float p_new = expf(s_new - m_run);
+            o = fmaf(p_new, qkv[2][tid], o);
+            l += p_new;
+        }
+        a.out[(size_t)img * inner + head * DH + tid] = Elem<T>::from_f32(o / l);
     }
 }
 

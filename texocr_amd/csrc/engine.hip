@@ -358,13 +358,27 @@ struct Engine : EngineBase {
         return 0;
     }
 
-    void launch_dec_attn(hipStream_t s, const T* K, const T* Vv, int lmax, int len, bool is_cross) {
-        DecAttnArgs<T> a{dq, K, Vv, dao, cfg.dec_heads, lmax, len, &st->t};
-        const int L = len >= 0 ? len : Tmax;
+    // fused attention front half: LN sandwich + q / qkv projection + cached single-query attention
+    void launch_dec_attn(hipStream_t s, bool cross, bool first, const T* W, T* K, T* Vv, int lmax, int len) {
+        DecAttnArgs<T> a{};
+        a.y = dy; a.tok = cur_tok; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = dx; a.gamma = dec_g; a.beta = dec_b;
+        a.D = D; a.W = W; a.K = K; a.V = Vv; a.out = dao; a.heads = cfg.dec_heads; a.lmax = lmax; a.len = len; a.t_ptr = &st->t;
+        const dim3 grid(sB * cfg.dec_heads), blk(256);
+        constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (prof && is_cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
-        hipLaunchKernelGGL((dec_attn_kernel<T>), dim3(sB * cfg.dec_heads), dim3(256), (size_t)L * sizeof(float), s, a);
-        if (prof && is_cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
+        if (prof && cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+        constexpr int WBS = sizeof(T) == 2 ? 3 : 1;        // self: q,k,v weight rows requested together (bf16) or one by one
+        const bool narrow = (D & 255) != 0;
+#define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
+        do {                                                                                                  \
+            if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, true>), grid, blk, 0, s, a);  \
+            else hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, false>), grid, blk, 0, s, a);        \
+        } while (0)
+        if (cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
+        else if (first) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
+        else TXO_DA(ATT_SELF, APRO_LN2, NLS, WBS);
+#undef TXO_DA
+        if (prof && cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
     }
 
     // one decode position on the stream; tokens/logits destinations are per call
@@ -379,32 +393,26 @@ struct Engine : EngineBase {
         const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)B * N * Id;
         for (int l = 0; l < cfg.dec_layers; ++l) {
             T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
-            {   // causal self attention
-                DecGemmArgs<T> a = base; a.N = 3 * Id; a.K = D; a.W = dec_self[l].wqkv; a.y = dy; a.x_out = dx;
-                a.k_cache = kc; a.v_cache = vc;
-                if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_QKV>(s, a) : launch_dec_gemm<PRO_LN2, EPI_QKV>(s, a))) return r;
-                dbg(s, "self qkv", l);
-                launch_dec_attn(s, kc, vc, Tmax, -1, false);
+            {   // causal self attention: LN sandwich + qkv projection + cache append + attention in one launch
+                launch_dec_attn(s, false, l == 0, dec_self[l].wqkv, kc, vc, Tmax, 0);
                 dbg(s, "self attn", l);
                 DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = dao;
                 o.resid = dx; o.y_out = dy;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
                 dbg(s, "self out", l);
             }
-            {   // cross attention over the cached encoder projections
-                DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy; a.x_out = dx;
-                if (int r = launch_dec_gemm<PRO_LN2, EPI_Q>(s, a)) return r;
-                dbg(s, "cross q", l);
-                launch_dec_attn(s, ckv + (size_t)(2 * l) * cross_stride, ckv + (size_t)(2 * l + 1) * cross_stride, N, N, true);
+            {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
+                launch_dec_attn(s, true, false, dec_cross[l].wq, ckv + (size_t)(2 * l) * cross_stride,
+                                ckv + (size_t)(2 * l + 1) * cross_stride, N, N);
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = dao;
                 o.resid = dx; o.y_out = dy;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+                dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
                 DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = dy; a.x_out = dx;
                 a.h_out = dhid; a.F = Fd;
-                dbg(s, "cross out", l);
                 if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
                 dbg(s, "ffn1", l);
                 DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = dhid;
