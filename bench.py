@@ -148,10 +148,17 @@ def main():
             sms, sn = eng.profile_read(2)
             eng.profile(False)
             algo = a.batch * dims.dec_heads * 2 * N * 64 * esz
+            traffic = None                      # PMC bytes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 passes
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bf16_b64.json")))["cross_attention_traffic"]
+                if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N}:
+                    traffic = pm["traffic_bytes"]
+            except Exception:
+                pass
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                                  "traffic": None, "algorithmic_bytes_per_launch": algo,
+                                  "traffic": traffic, "algorithmic_bytes_per_launch": algo,
                                   "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
                                   "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1)}
         if not a.no_cpu_baseline:

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -107,6 +108,23 @@ struct Engine : EngineBase {
     float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr;
     int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
     // ----- decode session -----
+    // A decode runs as 1..MAXL independent "lanes" (contiguous row ranges of the batch), each on its own HIP
+    // stream with its own step state, so the latency chains of one lane's small kernels overlap the other's.
+    // Every lane's step is a fixed launch sequence (the position lives on the device) -> captured once as a
+    // hipGraph and replayed per step.
+    static constexpr int MAXL = 4;
+    struct Lane {
+        int b0 = 0, nb = 0;
+        hipStream_t stream = nullptr;      // lane 0 runs on the caller's stream
+        hipStream_t own = nullptr;         // engine-owned stream for lanes > 0
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        int gb0 = -1, gnb = -1, gN = -1, geos = -2;   // what the captured graph was built for
+    };
+    Lane lanes[MAXL];
+    int n_lanes = 1, max_lanes = 2;
+    hipStream_t cap_stream = nullptr;      // graphs are captured here, never on the caller's stream
+    hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t* tok_buf = nullptr;            // [Bmax][Tmax] generated ids (engine-owned so graphs do not bake user pointers)
     int sB = 0, sN = 0; bool session = false;
     // ----- profiling -----
     bool prof = false; EventPool pool;
@@ -114,7 +132,17 @@ struct Engine : EngineBase {
 
     int D, Ie, Id, Fe, Fd, V, Tmax, Nmax, Bmax;
 
-    ~Engine() override { for (void* p : allocs) (void)hipFree(p); }
+    ~Engine() override {
+        for (auto& ln : lanes) {
+            if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
+            if (ln.graph) (void)hipGraphDestroy(ln.graph);
+            if (ln.own) (void)hipStreamDestroy(ln.own);
+        }
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
+        for (void* p : allocs) (void)hipFree(p);
+    }
 
     template <typename U> int dalloc(U** p, size_t n) {
         void* q = nullptr;
@@ -274,9 +302,17 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
-        if (int r = dalloc(&done_flag, (size_t)Tmax)) return r;
-        if (int r = dalloc(&st, 1)) return r;
-        HIP_TRY(hipMemset(st, 0, sizeof(StepState)));
+        if (int r = dalloc(&done_flag, (size_t)Tmax * MAXL)) return r;
+        if (int r = dalloc(&st, MAXL)) return r;
+        if (int r = dalloc(&tok_buf, (size_t)Bmax * Tmax)) return r;
+        HIP_TRY(hipMemset(st, 0, sizeof(StepState) * MAXL));
+        max_lanes = MAXL;
+        if (max_lanes < 1) max_lanes = 1;
+        if (max_lanes > MAXL) max_lanes = MAXL;
+        for (int i = 1; i < max_lanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&lanes[i].own, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         return 0;
     }
 
@@ -340,12 +376,35 @@ struct Engine : EngineBase {
         // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D]
         launch_gemm_big<T>(s, LoadPlain<T>{a_enc, D}, wckv, M, cfg.dec_layers * 2 * Id, D,
                            EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, N});
-        const int n = B > Tmax ? B : Tmax;
-        hipLaunchKernelGGL(reset_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, cur_tok, eos_seen, done_flag,
-                           B, Tmax, cfg.bos, eos);
-        HIP_TRY(hipGetLastError());
         sB = B; sN = N; session = true;
+        set_lanes(1, s);
+        reset_lanes(s, eos);
+        HIP_TRY(hipGetLastError());
         return 0;
+    }
+
+    // split the batch into n contiguous row ranges (multiples of 16 rows where possible)
+    void set_lanes(int n, hipStream_t s) {
+        const int tiles = (sB + 15) / 16;
+        if (n > tiles) n = tiles;
+        if (n < 1) n = 1;
+        n_lanes = n;
+        int row = 0;
+        for (int i = 0; i < n; ++i) {
+            const int tl = tiles / n + (i < tiles % n ? 1 : 0);
+            lanes[i].b0 = row;
+            lanes[i].nb = std::min(sB - row, tl * 16);
+            row += lanes[i].nb;
+            lanes[i].stream = i == 0 ? s : lanes[i].own;
+        }
+    }
+    void reset_lanes(hipStream_t s, int eos) {
+        for (int i = 0; i < n_lanes; ++i) {
+            const Lane& ln = lanes[i];
+            const int n = ln.nb > Tmax ? ln.nb : Tmax;
+            hipLaunchKernelGGL(reset_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st + i, cur_tok + ln.b0,
+                               eos_seen + ln.b0, done_flag + (size_t)i * Tmax, ln.nb, Tmax, cfg.bos, eos);
+        }
     }
 
     template <int PRO, int EPI>
@@ -359,11 +418,15 @@ struct Engine : EngineBase {
     }
 
     // fused attention front half: LN sandwich + q / qkv projection + cached single-query attention
-    void launch_dec_attn(hipStream_t s, bool cross, bool first, const T* W, T* K, T* Vv, int lmax, int len) {
+    void launch_dec_attn(hipStream_t s, int li, bool cross, bool first, const T* W, T* K, T* Vv, int lmax, int len) {
+        const Lane& ln = lanes[li];
+        const size_t r0 = ln.b0;
         DecAttnArgs<T> a{};
-        a.y = dy; a.tok = cur_tok; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = dx; a.gamma = dec_g; a.beta = dec_b;
-        a.D = D; a.W = W; a.K = K; a.V = Vv; a.out = dao; a.heads = cfg.dec_heads; a.lmax = lmax; a.len = len; a.t_ptr = &st->t;
-        const dim3 grid(sB * cfg.dec_heads), blk(256);
+        a.y = dy + r0 * D; a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = dx + r0 * D;
+        a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = W;
+        a.K = K + r0 * cfg.dec_heads * lmax * DH; a.V = Vv + r0 * cfg.dec_heads * lmax * DH;
+        a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = lmax; a.len = len; a.t_ptr = &st[li].t;
+        const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof && cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
@@ -381,54 +444,76 @@ struct Engine : EngineBase {
         if (prof && cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
     }
 
-    // one decode position on the stream; tokens/logits destinations are per call
-    int enqueue_step(hipStream_t s, int64_t* tokens_out, int out_stride, float* logits_out, int eos) {
-        const int B = sB, N = sN;
+    // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
+    int enqueue_step(hipStream_t s, int li, int64_t* tokens_out, int out_stride, float* logits_out, int eos) {
+        const Lane& ln = lanes[li];
+        const int B = sB, N = sN, nb = ln.nb;
+        const size_t r0 = ln.b0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
         DecGemmArgs<T> base{};
-        base.rows = B; base.gamma = dec_g; base.beta = dec_b; base.t_ptr = &st->t; base.D = D;
-        base.tok = cur_tok; base.tok_emb = tok_emb; base.pos_emb = pos_emb;
-        base.q_out = dq; base.inner = Id; base.heads = cfg.dec_heads; base.tmax = Tmax;
+        base.rows = nb; base.gamma = dec_g; base.beta = dec_b; base.t_ptr = &st[li].t; base.D = D;
+        base.inner = Id; base.heads = cfg.dec_heads; base.tmax = Tmax;
+        float* lx = dx + r0 * D; float* ly = dy + r0 * D; T* lao = dao + r0 * Id; T* lhid = dhid + r0 * Fd;
+        float* llog = dlogits + r0 * V;
         const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)B * N * Id;
         for (int l = 0; l < cfg.dec_layers; ++l) {
             T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
             {   // causal self attention: LN sandwich + qkv projection + cache append + attention in one launch
-                launch_dec_attn(s, false, l == 0, dec_self[l].wqkv, kc, vc, Tmax, 0);
+                launch_dec_attn(s, li, false, l == 0, dec_self[l].wqkv, kc, vc, Tmax, 0);
                 dbg(s, "self attn", l);
-                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = dao;
-                o.resid = dx; o.y_out = dy;
+                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = lao;
+                o.resid = lx; o.y_out = ly;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
                 dbg(s, "self out", l);
             }
             {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
-                launch_dec_attn(s, true, false, dec_cross[l].wq, ckv + (size_t)(2 * l) * cross_stride,
+                launch_dec_attn(s, li, true, false, dec_cross[l].wq, ckv + (size_t)(2 * l) * cross_stride,
                                 ckv + (size_t)(2 * l + 1) * cross_stride, N, N);
                 dbg(s, "cross attn", l);
-                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = dao;
-                o.resid = dx; o.y_out = dy;
+                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = lao;
+                o.resid = lx; o.y_out = ly;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
                 dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
-                DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = dy; a.x_out = dx;
-                a.h_out = dhid; a.F = Fd;
+                DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = ly; a.x_out = lx;
+                a.h_out = lhid; a.F = Fd;
                 if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
                 dbg(s, "ffn1", l);
-                DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = dhid;
-                o.resid = dx; o.y_out = dy;
+                DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = lhid;
+                o.resid = lx; o.y_out = ly;
                 if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, o)) return r;
             }
         }
-        DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.y = dy; f.gamma = decn_g; f.beta = decn_b;
-        f.logits = dlogits;
+        DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.y = ly; f.gamma = decn_g; f.beta = decn_b;
+        f.logits = llog;
         dbg(s, "ffn2 (last)");
         if (int r = launch_dec_gemm<PRO_LNF, EPI_LOGITS>(s, f)) return r;
         dbg(s, "logits");
-        StepArgs sa{dlogits, V, B, cur_tok, tokens_out, out_stride, logits_out, st, eos_seen, done_flag, eos};
-        hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
+        StepArgs sa{llog, V, nb, cur_tok + r0, tokens_out ? tokens_out + r0 * out_stride : nullptr, out_stride,
+                    logits_out ? logits_out + r0 * (size_t)out_stride * V : nullptr, st + li, eos_seen + r0,
+                    done_flag + (size_t)li * Tmax, eos};
+        hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
         dbg(s, "argmax");
         if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
+        return 0;
+    }
+
+    // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
+    int lane_graph(int li, int eos) {
+        Lane& ln = lanes[li];
+        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos) return 0;
+        if (ln.exec) { (void)hipGraphExecDestroy(ln.exec); ln.exec = nullptr; }
+        if (ln.graph) { (void)hipGraphDestroy(ln.graph); ln.graph = nullptr; }
+        hipStream_t cs = cap_stream;
+        HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        const int r = enqueue_step(cs, li, tok_buf, Tmax, nullptr, eos);
+        hipError_t e = hipStreamEndCapture(cs, &ln.graph);
+        if (r) return r;
+        if (e != hipSuccess) return fail(TXO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+        HIP_TRY(hipGraphInstantiate(&ln.exec, ln.graph, nullptr, nullptr, 0));
+        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos;
         return 0;
     }
 
@@ -437,9 +522,11 @@ struct Engine : EngineBase {
         if (t < 0 || t >= Tmax)
             return fail(TXO_E_INVALID, "position outside the decoder's positional table (the reference would slide its "
                                        "window, decoder.py:99-100; a KV cache cannot reproduce that)");
+        if (n_lanes != 1) return fail(TXO_E_STATE, "decode_step needs a session started by txo_decode_begin");
+        lanes[0].stream = s;
         if (tok_in) HIP_TRY(hipMemcpyAsync(cur_tok, tok_in, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, t);
-        if (int r = enqueue_step(s, nullptr, 0, nullptr, -1)) return r;
+        if (int r = enqueue_step(s, 0, nullptr, 0, nullptr, -1)) return r;
         if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, dlogits, sizeof(float) * sB * V, hipMemcpyDeviceToDevice, s));
         if (tok_out) HIP_TRY(hipMemcpyAsync(tok_out, cur_tok, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipGetLastError());
@@ -457,22 +544,58 @@ struct Engine : EngineBase {
             enc = eenc; N = 1 + (H / 16) * (W / 16);
         }
         if (int r = decode_begin(enc, B, N, eos, s)) return r;   // eos also decides whether the BOS column counts
-        std::vector<int> flags(max_len);
+        // lanes: graphs + extra streams unless per-step logits were asked for or a debug/profiling mode is on
+        // Measured on MI355X (B=64, 224x672, T=256): the step is bound by the GPU-side latency chain of its ~26
+        // dependent launches, not by the host -- graph replay and 2-4 lanes give the same wall time as eager
+        // single-stream launches (57.1 vs 58.0 / 58.2 ms) -- so both stay opt-in: TXO_GRAPH=1, TXO_LANES=n.
+        const bool eager = logits_out != nullptr || g_dbg || getenv("TXO_GRAPH") == nullptr;
+        int want = 1;
+        if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
+        if (B < 32) want = 1;
+        set_lanes(want, s);
+        reset_lanes(s, eos);
+        bool use_graph = !eager && !prof;
+        if (use_graph) for (int i = 0; i < n_lanes; ++i) if (int r = lane_graph(i, eos)) return r;
+        if (n_lanes > 1) {
+            HIP_TRY(hipEventRecord(ev_fork, s));
+            for (int i = 1; i < n_lanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
+        }
+        int64_t* tdst = use_graph ? tok_buf : tokens_out;
+        const int tstride = use_graph ? Tmax : max_len;
+        std::vector<int> flags((size_t)MAXL * Tmax, 0);
         const int CHUNK = 32;
         int steps = max_len;
         for (int t = 0; t < max_len; ++t) {
-            if (int r2 = enqueue_step(s, tokens_out, max_len, logits_out, eos)) return r2;
+            for (int i = 0; i < n_lanes; ++i) {
+                if (use_graph) HIP_TRY(hipGraphLaunch(lanes[i].exec, lanes[i].stream));
+                else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos)) return r2;
+            }
             if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
                 const int lo = (t / CHUNK) * CHUNK;
-                HIP_TRY(hipMemcpyAsync(flags.data() + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
+                for (int i = 0; i < n_lanes; ++i)
+                    HIP_TRY(hipMemcpyAsync(flags.data() + (size_t)i * Tmax + lo, done_flag + (size_t)i * Tmax + lo,
+                                           sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, lanes[i].stream));
+                for (int i = 0; i < n_lanes; ++i) HIP_TRY(hipStreamSynchronize(lanes[i].stream));
                 bool stop = false;
-                for (int i = lo; i <= t; ++i) if (flags[i]) { steps = i + 1; stop = true; break; }
+                for (int k = lo; k <= t && !stop; ++k) {
+                    bool all = true;
+                    for (int i = 0; i < n_lanes; ++i) all = all && flags[(size_t)i * Tmax + k];
+                    if (all) { steps = k + 1; stop = true; }
+                }
                 if (stop) break;
             }
         }
+        // join the lanes back into the caller's stream
+        for (int i = 1; i < n_lanes; ++i) {
+            HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
+            HIP_TRY(hipStreamWaitEvent(s, ev_join[i], 0));
+        }
+        if (use_graph)
+            HIP_TRY(hipMemcpy2DAsync(tokens_out, sizeof(int64_t) * max_len, tok_buf, sizeof(int64_t) * Tmax,
+                                     sizeof(int64_t) * max_len, B, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
+        set_lanes(1, s);
         if (n_steps) *n_steps = steps;
         return 0;
     }
