@@ -28,7 +28,8 @@
 namespace txo {
 
 enum { ATT_CROSS = 0, ATT_SELF = 1 };
-enum { APRO_EMBED = 0, APRO_LN2 = 1 };
+// APRO_NONE: no prologue / projection in this launch -- q comes from a.qin and (self) row t is already in the cache
+enum { APRO_EMBED = 0, APRO_LN2 = 1, APRO_NONE = 2 };
 
 template <typename T> struct DecAttnArgs {
     // row prologue
@@ -38,6 +39,7 @@ template <typename T> struct DecAttnArgs {
     const float* gamma; const float* beta;
     int D;
     const T* W;                     // cross: Wq [inner][D]; self: Wqkv [3*inner][D]
+    const float* qin;               // APRO_NONE: [images][heads*64] fp32 query
     // attention
     T* K; T* V;                     // [images*heads][lmax][64]; self mode appends row t
     T* out;                         // [images][heads*64]
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     constexpr int LPR = DH / PER16;          // lanes per 64-element row: 16 (f32) / 8 (bf16)
     constexpr int KPI = 64 / LPR;            // keys per wave-instruction: 4 / 8
     constexpr int KPB = KPI * 4;             // keys per block-instruction (four waves)
+    constexpr bool FUSED = APRO != APRO_NONE;
     constexpr int NP = MODE == ATT_SELF ? 3 : 1;
     constexpr int NVMAX = 3;                 // row prologue: D <= 768 (one wave, float4 per lane per 256)
     constexpr int WMAX = 8;                  // weight pieces per thread per projection per group (bf16: one group at D = 256)
@@ -123,23 +126,31 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
             for (int i = 0; i < WMAX; ++i) wreg[p][i] = ld16(wrow + min(prt + 4 * (g * WMAX + i), pieces - 1) * PER16);
         }
     };
-    issue_w(0, 0);
+    if constexpr (FUSED) issue_w(0, 0);
 
     // ---- 1. request the K panel of the first pass ----
     int t = 0;
     if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = *a.t_ptr;
-    const int L = MODE == ATT_CROSS ? a.len : t;             // cached keys (self: the new key t is handled apart)
+    // cached keys: fused self handles the new key t apart; plain self finds it in the cache already
+    const int L = MODE == ATT_CROSS ? a.len : (FUSED ? t : t + 1);
     const int Lm1 = max(L - 1, 0);
     const int key0 = wave * KPI + kq;
     u32x4 rk[NL], rv[NL];
+    // small panels (self attention) request V together with K; long ones (cross) request each V row as its K
+    // registers are consumed, which halves the live panel (K and V of NL = 20 would not fit 256 VGPRs)
+    constexpr bool V_EARLY = MODE == ATT_SELF;
     auto issue_k = [&](int base) {
 #pragma unroll
         for (int u = 0; u < NL; ++u) rk[u] = ld16(Kb + (size_t)min(base + u * KPB + key0, Lm1) * DH + sub * PER16);
+        if constexpr (V_EARLY) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) rv[u] = ld16(Vb + (size_t)min(base + u * KPB + key0, Lm1) * DH + sub * PER16);
+        }
     };
     issue_k(0);
 
     // ---- 2. row prologue (wave 0): x = LN(y) | emb ; z = LN(x) -> LDS ----
-    if (wave == 0) {
+    if (FUSED && wave == 0) {
         const float inv_d = 1.0f / D;
         if constexpr (!NARROW) {
             const int nv = D >> 8;
@@ -203,11 +214,11 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
             for (int i = 0; i < 12; ++i) if (i < ne) { const int c = i * 64 + lane; if (c < D) zs[c] = vals[i]; }
         }
     }
-    __syncthreads();
+    if constexpr (FUSED) __syncthreads();
 
     // ---- 3. projection from the weight pieces already in flight ----
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += WB) {
+    for (int p0 = 0; p0 < (FUSED ? NP : 0); p0 += WB) {
         float accp[WB];
 #pragma unroll
         for (int p = 0; p < WB; ++p) accp[p] = 0.f;
@@ -238,9 +249,9 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
             if (prt == 0) qkv[p0 + p][pd] = v;
         }
     }
-    __syncthreads();
+    if constexpr (FUSED) __syncthreads();
     float s_new = 0.f;                                        // self: score of the new key t
-    if constexpr (MODE == ATT_SELF) {
+    if constexpr (MODE == ATT_SELF && FUSED) {
         // append k_t, v_t (rounded to the cache type, exactly what later steps will read back)
         if (tid < 2 * DH) {
             const int which = tid >> 6, dd = tid & 63;
@@ -255,10 +266,11 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     // this lane's 16-byte piece of the query, pre-scaled (0.125 is exact)
     float qv[PER16];
 #pragma unroll
-    for (int e = 0; e < PER16; ++e) qv[e] = qkv[0][sub * PER16 + e] * ATTN_SCALE;
+    for (int e = 0; e < PER16; ++e)
+        qv[e] = (FUSED ? qkv[0][sub * PER16 + e] : a.qin[(size_t)img * inner + head * DH + sub * PER16 + e]) * ATTN_SCALE;
 
     // ---- 4. passes over the panel (one pass when len <= NL*KPB) ----
-    float m_run = MODE == ATT_SELF ? s_new : -3.0e38f, l_run = 0.f;
+    float m_run = (MODE == ATT_SELF && FUSED) ? s_new : -3.0e38f, l_run = 0.f;
     float acc[PER16];
 #pragma unroll
     for (int e = 0; e < PER16; ++e) acc[e] = 0.f;
@@ -275,14 +287,14 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
 #pragma unroll
             for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
             // the K registers of this slot are dead now: request the matching V rows into their place
-            rv[u] = ld16(Vb + (size_t)min(key, Lm1) * DH + sub * PER16);
+            if constexpr (!V_EARLY) rv[u] = ld16(Vb + (size_t)min(key, Lm1) * DH + sub * PER16);
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // butterfly: all LPR lanes get the dot
             d = key < L ? d : -3.0e38f;
             sc[u] = d;
             mx = fmaxf(mx, d);
             // keep the V requests in program order behind the K consumption (else both panels are live at once)
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!V_EARLY) __builtin_amdgcn_sched_barrier(0);
         }
         mx = wave_max(mx);
         if (lane == 0) stat[slot * 4 + wave] = mx;
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     if (tid < DH) {
         float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         float l = (stat[8] + stat[9]) + (stat[10] + stat[11]);
-        if constexpr (MODE == ATT_SELF) {
+        if constexpr (MODE == ATT_SELF && FUSED) {
             const float p_new = expf(s_new - m_run);
             o = fmaf(p_new, qkv[2][tid], o);
             l += p_new;

@@ -122,6 +122,7 @@ struct Engine : EngineBase {
     };
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
+    bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     hipStream_t cap_stream = nullptr;      // graphs are captured here, never on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
     int64_t* tok_buf = nullptr;            // [Bmax][Tmax] generated ids (engine-owned so graphs do not bake user pointers)
@@ -417,31 +418,38 @@ struct Engine : EngineBase {
         return 0;
     }
 
-    // fused attention front half: LN sandwich + q / qkv projection + cached single-query attention
-    void launch_dec_attn(hipStream_t s, int li, bool cross, bool first, const T* W, T* K, T* Vv, int lmax, int len) {
+    // attention front half: (optional) row prologue + q / qkv projection + cached single-query attention
+    struct AttnOpt {
+        bool cross = false; int apro = APRO_LN2;
+        const T* W = nullptr; T* K = nullptr; T* V = nullptr; int lmax = 0, len = 0;
+        float* x_out = nullptr;
+    };
+    void launch_dec_attn(hipStream_t s, int li, const AttnOpt& o) {
         const Lane& ln = lanes[li];
         const size_t r0 = ln.b0;
         DecAttnArgs<T> a{};
-        a.y = dy + r0 * D; a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = dx + r0 * D;
-        a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = W;
-        a.K = K + r0 * cfg.dec_heads * lmax * DH; a.V = Vv + r0 * cfg.dec_heads * lmax * DH;
-        a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = lmax; a.len = len; a.t_ptr = &st[li].t;
+        a.y = dy + r0 * D; a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = o.x_out;
+        a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = o.W;
+        a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
+        a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t;
+        a.qin = dq + r0 * Id;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (prof && cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
         constexpr int WBS = sizeof(T) == 2 ? 3 : 1;        // self: q,k,v weight rows requested together (bf16) or one by one
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (prof && o.cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
         const bool narrow = (D & 255) != 0;
 #define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
         do {                                                                                                  \
             if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, true>), grid, blk, 0, s, a);  \
             else hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, false>), grid, blk, 0, s, a);        \
         } while (0)
-        if (cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
-        else if (first) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
+        if (o.cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
+        else if (o.apro == APRO_NONE) TXO_DA(ATT_SELF, APRO_NONE, NLS, 1);
+        else if (o.apro == APRO_EMBED) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
         else TXO_DA(ATT_SELF, APRO_LN2, NLS, WBS);
 #undef TXO_DA
-        if (prof && cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
+        if (prof && o.cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
     }
 
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
@@ -459,21 +467,36 @@ struct Engine : EngineBase {
         const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)B * N * Id;
         for (int l = 0; l < cfg.dec_layers; ++l) {
             T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
-            {   // causal self attention: LN sandwich + qkv projection + cache append + attention in one launch
-                launch_dec_attn(s, li, false, l == 0, dec_self[l].wqkv, kc, vc, Tmax, 0);
+            {   // causal self attention
+                AttnOpt o; o.W = dec_self[l].wqkv; o.K = kc; o.V = vc; o.lmax = Tmax; o.x_out = lx;
+                if (self_plain) {
+                    // default: LN sandwich + QKV GEMM (weights read once per 16 rows; k/v appended to the cache by
+                    // its epilogue), then the plain cached attention.  TXO_SELF_FUSED=1 folds the projection into
+                    // the attention launch instead (same wall time at B=64; re-reads 96 KB of weights per image).
+                    DecGemmArgs<T> a = base; a.N = 3 * Id; a.K = D; a.W = dec_self[l].wqkv; a.y = ly; a.x_out = lx;
+                    a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb;
+                    a.q_out = dq + r0 * Id;
+                    a.k_cache = kc + r0 * cfg.dec_heads * Tmax * DH; a.v_cache = vc + r0 * cfg.dec_heads * Tmax * DH;
+                    if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_QKV>(s, a) : launch_dec_gemm<PRO_LN2, EPI_QKV>(s, a))) return r;
+                    o.apro = APRO_NONE;
+                } else {
+                    o.apro = l == 0 ? APRO_EMBED : APRO_LN2;
+                }
+                launch_dec_attn(s, li, o);
                 dbg(s, "self attn", l);
-                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_self[l].wo; o.bias = dec_self[l].bo; o.A = lao;
-                o.resid = lx; o.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+                DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_self[l].wo; g.bias = dec_self[l].bo; g.A = lao;
+                g.resid = lx; g.y_out = ly;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r;
                 dbg(s, "self out", l);
             }
             {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
-                launch_dec_attn(s, li, true, false, dec_cross[l].wq, ckv + (size_t)(2 * l) * cross_stride,
-                                ckv + (size_t)(2 * l + 1) * cross_stride, N, N);
+                AttnOpt o; o.cross = true; o.W = dec_cross[l].wq; o.K = ckv + (size_t)(2 * l) * cross_stride;
+                o.V = ckv + (size_t)(2 * l + 1) * cross_stride; o.lmax = N; o.len = N; o.x_out = lx;
+                launch_dec_attn(s, li, o);
                 dbg(s, "cross attn", l);
-                DecGemmArgs<T> o = base; o.N = 2 * D; o.K = Id; o.W = dec_cross[l].wo; o.bias = dec_cross[l].bo; o.A = lao;
-                o.resid = lx; o.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, o)) return r;
+                DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
+                g.resid = lx; g.y_out = ly;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r;
                 dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
@@ -481,14 +504,13 @@ struct Engine : EngineBase {
                 a.h_out = lhid; a.F = Fd;
                 if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
                 dbg(s, "ffn1", l);
-                DecGemmArgs<T> o = base; o.N = D; o.K = Fd; o.W = dec_mlp[l].w2; o.bias = dec_mlp[l].b2; o.A = lhid;
-                o.resid = lx; o.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, o)) return r;
+                DecGemmArgs<T> g = base; g.N = D; g.K = Fd; g.W = dec_mlp[l].w2; g.bias = dec_mlp[l].b2; g.A = lhid;
+                g.resid = lx; g.y_out = ly;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, g)) return r;
             }
         }
-        DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.y = ly; f.gamma = decn_g; f.beta = decn_b;
-        f.logits = llog;
-        dbg(s, "ffn2 (last)");
+        DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.logits = llog;
+        f.y = ly; f.gamma = decn_g; f.beta = decn_b;
         if (int r = launch_dec_gemm<PRO_LNF, EPI_LOGITS>(s, f)) return r;
         dbg(s, "logits");
         StepArgs sa{llog, V, nb, cur_tok + r0, tokens_out ? tokens_out + r0 * out_stride : nullptr, out_stride,
