@@ -29,6 +29,9 @@ extern "C" {
 #define TXO_E_STATE (-2)     /* call order / missing weights (maps to RuntimeError)    */
 #define TXO_E_HIP (-3)       /* HIP runtime error (maps to RuntimeError)               */
 
+#define TXO_EMBED_PATCH 0
+#define TXO_EMBED_HYBRID 1
+
 #define TXO_F32 0            /* parity mode: f32 storage, exact-f32 MFMA               */
 #define TXO_BF16 1           /* perf mode: bf16 weights / K,V caches / GEMM operands, f32 accumulate */
 
@@ -37,8 +40,11 @@ typedef struct txo_engine txo_engine;
 /* Mirrors the values create_model(config) reads (model/ocr_model.py:113-130, model/encoder.py:172-191,
  * model/decoder.py:148-173) plus capacity limits for the engine-owned buffers. */
 typedef struct txo_config {
-    int32_t canvas;        /* VisionTransformer img_size (square max canvas, pixels), encoder.py:95      */
-    int32_t in_channels;   /* PatchEmbedding in_channels, encoder.py:13                                   */
+    int32_t canvas_h;      /* VisionTransformer img_size: max canvas height, pixels (encoder.py:95)       */
+    int32_t canvas_w;      /* ... and width; the hybrid factory uses (160, 1008) (encoder.py:183)         */
+    int32_t embed;         /* TXO_EMBED_PATCH: PatchEmbedding (encoder.py:11-28) | TXO_EMBED_HYBRID:
+                              ResNetV2 [2,4,6] backbone + 1x1 proj, what create_encoder builds (:162-191) */
+    int32_t in_channels;   /* image channels (PatchEmbedding in_channels; the hybrid embedder needs 1)    */
     int32_t embed_dim;     /* encoder == decoder width (no enc->dec projection, attention.py:89-91)       */
     int32_t enc_heads, enc_layers, dec_heads, dec_layers;
     int32_t enc_exp, dec_exp;   /* FFN expansion (MLP exp_factor, attention.py:46)                        */
@@ -47,7 +53,7 @@ typedef struct txo_config {
     int32_t bos, eos, pad; /* config bos_token / eos_token / trg_pad_idx                                  */
     int32_t dtype;         /* TXO_F32 | TXO_BF16                                                          */
     int32_t max_batch;     /* capacity: images per call                                                   */
-    int32_t max_tokens;    /* capacity: encoder tokens per image (<= 1 + (canvas/16)^2); 0 = that maximum */
+    int32_t max_tokens;    /* capacity: encoder tokens per image (<= 1 + canvas_h*canvas_w/256); 0 = that maximum */
 } txo_config;
 
 /* OCRModel.__init__ / create_model (ocr_model.py:16-32,113-130): allocate the engine. */

@@ -33,7 +33,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from texocr_amd.config import Dims, default_config          # noqa: E402
+from texocr_amd.config import Dims, default_config, reference_config          # noqa: E402
 from texocr_amd import synth                                 # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -51,13 +51,13 @@ def import_reference():
     sys.modules["torchvision.transforms"] = tv.transforms
     from TeXOCR.model.encoder import VisionEncoder
     from TeXOCR.model.decoder import create_decoder
-    from TeXOCR.model.ocr_model import OCRModel
+    from TeXOCR.model.ocr_model import OCRModel, create_model
     import TeXOCR.model.decoder as dec_mod
     import TeXOCR.utils as ref_utils
-    return VisionEncoder, create_decoder, OCRModel, dec_mod, ref_utils
+    return VisionEncoder, create_decoder, OCRModel, dec_mod, ref_utils, create_model
 
 
-VisionEncoder, create_decoder, OCRModel, ref_dec_mod, ref_utils = import_reference()
+VisionEncoder, create_decoder, OCRModel, ref_dec_mod, ref_utils, ref_create_model = import_reference()
 
 
 def build_reference(d: Dims, seed: int):
@@ -310,7 +310,41 @@ def cap_sampling():
          logits=logits.numpy(), probs=probs.numpy())
 
 
-CAPS = {"tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
+@torch.no_grad()
+def cap_hybrid():
+    """N1: the default factory create_model(config/config.yml): hybrid ResNetV2 [2,4,6] embedder, 1 channel,
+    (160, 1008) canvas.  Two 1x32x96 images (12 tokens + CLS), 12 greedy steps; per-stage backbone features."""
+    cfg = reference_config()
+    cfg["device"] = "cpu"
+    d = Dims.from_config(cfg)
+    seed, img_seed = 5, 77
+    model = ref_create_model({k: v for k, v in cfg.items() if k not in ("embed",)}).eval()
+    sd_np = synth.synth_state_dict(d, seed)
+    ref_sd = model.state_dict()
+    assert set(ref_sd.keys()) == set(sd_np.keys()), set(ref_sd.keys()) ^ set(sd_np.keys())
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == sd_np[k].shape, (k, v.shape, sd_np[k].shape)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    img = torch.from_numpy(synth.synth_images(2, 1, 32, 96, img_seed))
+    bb = model.encoder.patch_embed.backbone_net
+    stem = bb.stem(img)
+    s0 = bb.stages[0](stem)
+    s1 = bb.stages[1](s0)
+    s2 = bb.stages[2](s1)
+    emb = model.encoder.patch_embed(img)
+    enc = model.encoder(img)
+    with greedy_patch() as gp:
+        toks = model.generate(img, max_len=12)
+    step_logits = torch.stack(gp.logits, 1)
+    layout = [[k, list(s), c] for k, s, c in synth.state_dict_layout(d)]
+    save("hybrid_b2_32x96", {"dims": d.to_dict(), "weight_seed": seed, "image_seed": img_seed, "image_shape": [2, 1, 32, 96],
+                             "max_len": 12, "n_state_dict_keys": len(layout),
+                             "note": "stem/stage features are NCHW as the reference produces them"},
+         stem=stem.numpy(), stage0=s0.numpy(), stage1=s1.numpy(), stage2=s2.numpy(), embed=emb.numpy(), enc=enc.numpy(),
+         tokens=toks.numpy().astype(np.int16), step_logits=step_logits.numpy(), margin=margins(step_logits))
+
+
+CAPS = {"hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
         "window": cap_window, "sampling": cap_sampling}
 
 if __name__ == "__main__":

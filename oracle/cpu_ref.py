@@ -147,12 +147,68 @@ def patch_embed(sd: SD, img: torch.Tensor) -> torch.Tensor:
     return x.flatten(2).transpose(1, 2)
 
 
-def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None) -> torch.Tensor:
-    """VisionTransformer.forward (encoder.py:128-152), head = Identity."""
+# ---- hybrid CNN embedder (the default factory's front end) ------------------------------------------
+def _same_pad(x: torch.Tensor, k: int, s: int, value: float = 0.0) -> torch.Tensor:
+    """utils.pad_same / get_same_padding (utils.py:97-99,112-123): TF-style SAME, extra pixel bottom/right."""
+    ih, iw = x.shape[-2:]
+    ph = max((math.ceil(ih / s) - 1) * s + (k - 1) + 1 - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + (k - 1) + 1 - iw, 0)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=value)
+    return x
+
+
+def std_conv(x: torch.Tensor, w: torch.Tensor, stride: int) -> torch.Tensor:
+    """StdConv2d.forward (resnet.py:54-66): weights standardised per output channel (biased variance, eps 1e-6);
+    static symmetric padding when stride == 1 and (k-1) even (utils.py:101-110), dynamic SAME otherwise."""
+    k = w.shape[-1]
+    # same ATen call as the reference, so the standardised weights are bit-identical to its
+    ws = F.batch_norm(w.reshape(1, w.shape[0], -1), None, None, training=True, momentum=0.0, eps=1e-6).reshape_as(w)
+    if stride == 1 and (k - 1) % 2 == 0:
+        return F.conv2d(x, ws, None, 1, (k - 1) // 2)
+    return F.conv2d(_same_pad(x, k, stride), ws, None, stride, 0)
+
+
+def group_norm_act(sd: SD, p: str, x: torch.Tensor, act: bool) -> torch.Tensor:
+    """GroupNormAct (resnet.py:14-35): 32 groups, eps 1e-5, optional ReLU."""
+    x = F.group_norm(x, 32, sd[f"{p}.weight"], sd[f"{p}.bias"], 1e-5)
+    return F.relu(x) if act else x
+
+
+def resnet_backbone(sd: SD, p: str, img: torch.Tensor) -> torch.Tensor:
+    """ResNetV2(depths=[2,4,6]).forward (resnet.py:200-254) with Bottleneck.forward (:143-149)."""
+    x = std_conv(img, sd[f"{p}.stem.0.weight"], 2)
+    x = group_norm_act(sd, f"{p}.stem.1", x, True)
+    x = F.max_pool2d(_same_pad(x, 3, 2, value=-float("inf")), 3, 2)                 # resnet.py:69-79
+    for st, depth in enumerate((2, 4, 6)):
+        for i in range(depth):
+            b = f"{p}.stages.{st}.stage_blocks.{i}"
+            stride = 2 if (i == 0 and st > 0) else 1
+            res = x
+            if f"{b}.downsample.conv.weight" in sd:
+                res = group_norm_act(sd, f"{b}.downsample.norm", std_conv(x, sd[f"{b}.downsample.conv.weight"], stride), False)
+            y = group_norm_act(sd, f"{b}.block_list.1", std_conv(x, sd[f"{b}.block_list.0.weight"], 1), True)
+            y = group_norm_act(sd, f"{b}.block_list.3", std_conv(y, sd[f"{b}.block_list.2.weight"], stride), True)
+            y = group_norm_act(sd, f"{b}.block_list.5", std_conv(y, sd[f"{b}.block_list.4.weight"], 1), False)
+            x = F.relu(y + res)
+    return x
+
+
+def hybrid_embed(sd: SD, img: torch.Tensor) -> torch.Tensor:
+    """HybridEmbedding.forward (encoder.py:65-72): backbone, 1x1 proj conv (+bias), flatten(2).transpose(1,2)."""
+    f = resnet_backbone(sd, "encoder.patch_embed.backbone_net", img)
+    f = F.conv2d(f, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"])
+    return f.flatten(2).transpose(1, 2)
+
+
+def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None, grid_w: Optional[int] = None) -> torch.Tensor:
+    """VisionTransformer.forward (encoder.py:128-152), head = Identity.  grid_w = patches per row of the max
+    canvas (canvas_w / 16); defaults to a square canvas."""
     B, C, H, W = img.shape
-    P = sd["encoder.patch_embed.proj.weight"].shape[-1]
-    grid = int(round(math.sqrt(sd["encoder.pos_embed"].shape[1] - 1)))
-    x = patch_embed(sd, img)
+    hybrid = "encoder.patch_embed.backbone_net.stem.0.weight" in sd
+    P = 16 if hybrid else sd["encoder.patch_embed.proj.weight"].shape[-1]
+    grid = grid_w or int(round(math.sqrt(sd["encoder.pos_embed"].shape[1] - 1)))
+    x = hybrid_embed(sd, img) if hybrid else patch_embed(sd, img)
     x = torch.cat([sd["encoder.cls_token"].expand(B, -1, -1), x], dim=1)    # :133-134
     x = x + sd["encoder.pos_embed"][:, pos_ids(H // P, W // P, grid)]       # :143
     x = stack(sd, "encoder.attn_layers", kinds_of(sd, "encoder.attn_layers"), x, None, False, trace)
@@ -188,11 +244,11 @@ def _all_rows_have_eos(output: torch.Tensor, eos: Optional[int]) -> bool:
 
 @torch.no_grad()
 def generate_recompute(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
-                       net_max_len: Optional[int] = None, collect_logits: bool = False):
+                       net_max_len: Optional[int] = None, collect_logits: bool = False, grid_w: Optional[int] = None):
     """The reference algorithm as written: full-prefix recompute each step, cross K/V
     re-projected each step, sliding window (ocr_model.py:46-66, decoder.py:77-122), with the
     sampler replaced by argmax (greedy; argmax survives top-k and softmax(/temp))."""
-    enc = encode(sd, img)
+    enc = encode(sd, img, grid_w=grid_w)
     B = img.shape[0]
     net_max_len = net_max_len or sd["decoder.net.pos_embedding.embedding.weight"].shape[0]
     output = torch.full((B, 1), bos, dtype=torch.long)                      # ocr_model.py:57

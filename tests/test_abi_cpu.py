@@ -29,7 +29,7 @@ def test_header_symbols_all_exported(lib):
 
 def _cfg(**over):
     from texocr_amd import _lib
-    base = dict(canvas=224, in_channels=3, embed_dim=256, enc_heads=8, enc_layers=4, dec_heads=8, dec_layers=4,
+    base = dict(canvas_h=224, canvas_w=224, embed=0, in_channels=3, embed_dim=256, enc_heads=8, enc_layers=4, dec_heads=8, dec_layers=4,
                 enc_exp=4, dec_exp=4, vocab=1000, max_len=256, bos=998, eos=997, pad=999, dtype=0, max_batch=4,
                 max_tokens=0)
     base.update(over)
@@ -37,7 +37,7 @@ def _cfg(**over):
 
 
 @pytest.mark.parametrize("over,frag", [
-    (dict(canvas=100), "canvas"), (dict(embed_dim=100), "embed_dim"), (dict(embed_dim=1024), "embed_dim"),
+    (dict(canvas_h=100), "canvas"), (dict(embed=1, in_channels=3), "hybrid"), (dict(embed_dim=100), "embed_dim"), (dict(embed_dim=1024), "embed_dim"),
     (dict(dtype=7), "dtype"), (dict(max_batch=0), "max_batch"), (dict(bos=5000), "bos"),
     (dict(max_tokens=100000), "max_tokens"), (dict(enc_layers=0), "layers"),
 ])

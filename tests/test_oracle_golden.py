@@ -141,3 +141,23 @@ def test_sampling_distribution():
     filt = cpu_ref.topk_filter(logits)
     assert int((filt[0] > -float("inf")).sum()) == meta["support"] == 99
     np.testing.assert_allclose(cpu_ref.sample_probs(logits, meta["temp"]).numpy(), g["probs"], atol=1e-7)
+
+
+def test_hybrid_default_factory_every_stage():
+    """N1: create_model(config/config.yml) -- ResNetV2 [2,4,6] hybrid embedder, (160, 1008) canvas."""
+    meta, g = load_golden("hybrid_b2_32x96")
+    d, sd, img = model_of(meta)
+    assert d.embed == "hybrid" and d.canvas_hw == (160, 1008) and meta["n_state_dict_keys"] == 372
+    p = "encoder.patch_embed.backbone_net"
+    x = cpu_ref.std_conv(img, sd[f"{p}.stem.0.weight"], 2)
+    x = cpu_ref.group_norm_act(sd, f"{p}.stem.1", x, True)
+    x = torch.nn.functional.max_pool2d(cpu_ref._same_pad(x, 3, 2, value=-float("inf")), 3, 2)
+    np.testing.assert_allclose(x.numpy(), g["stem"], atol=2e-5)
+    f = cpu_ref.resnet_backbone(sd, p, img)
+    np.testing.assert_allclose(f.numpy(), g["stage2"], atol=5e-5)
+    np.testing.assert_allclose(cpu_ref.hybrid_embed(sd, img).numpy(), g["embed"], atol=5e-5)
+    enc = cpu_ref.encode(sd, img, grid_w=d.grid)
+    np.testing.assert_allclose(enc.numpy(), g["enc"], atol=5e-5)
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, meta["max_len"], collect_logits=True, enc=enc)
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    np.testing.assert_allclose(logits.numpy(), g["step_logits"], atol=5e-5)

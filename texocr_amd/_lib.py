@@ -17,7 +17,7 @@ TXO_E_INVALID, TXO_E_STATE, TXO_E_HIP = -1, -2, -3
 
 class TxoConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "canvas", "in_channels", "embed_dim", "enc_heads", "enc_layers", "dec_heads", "dec_layers",
+        "canvas_h", "canvas_w", "embed", "in_channels", "embed_dim", "enc_heads", "enc_layers", "dec_heads", "dec_layers",
         "enc_exp", "dec_exp", "vocab", "max_len", "bos", "eos", "pad", "dtype", "max_batch", "max_tokens")]
 
 

@@ -16,9 +16,16 @@ DIM_HEAD = 64  # reference model/attention.py:76 -- never overridden by Attentio
 PATCH = 16
 
 
+RESNET_DEPTHS = (2, 4, 6)          # create_encoder hard-wires ResNetV2(depths=[2,4,6]) (encoder.py:177-180)
+RESNET_CHANNELS = (256, 512, 1024)  # ResNetV2 default channels (resnet.py:204)
+HYBRID_CANVAS = (160, 1008)        # create_encoder's img_size (encoder.py:183)
+
+
 @dataclass(frozen=True)
 class Dims:
-    canvas: int = 672          # square max canvas in pixels (VisionTransformer img_size, encoder.py:95)
+    canvas: int = 672          # square max canvas in pixels (VisionTransformer img_size, encoder.py:95) ...
+    canvas_w: int = 0          # ... or canvas x canvas_w when non-zero (the hybrid factory uses 160 x 1008)
+    embed: str = "patch"       # "patch": PatchEmbedding (encoder.py:11-28) | "hybrid": ResNetV2 [2,4,6] + 1x1 proj (:31-72,162-191)
     in_channels: int = 3
     embed_dim: int = 256       # encoder and decoder width must match (no enc->dec projection, attention.py:89-91)
     enc_heads: int = 8
@@ -36,12 +43,21 @@ class Dims:
 
     # derived ---------------------------------------------------------------
     @property
-    def grid(self) -> int:
+    def canvas_hw(self):
+        return (self.canvas, self.canvas_w or self.canvas)
+
+    @property
+    def grid_h(self) -> int:
         return self.canvas // self.patch
 
     @property
+    def grid(self) -> int:
+        """patches per row of the max canvas (the stride of the position-id grid, encoder.py:137-139)"""
+        return (self.canvas_w or self.canvas) // self.patch
+
+    @property
     def n_pos(self) -> int:
-        return 1 + self.grid * self.grid
+        return 1 + self.grid_h * self.grid
 
     @property
     def enc_inner(self) -> int:
@@ -67,8 +83,9 @@ class Dims:
             raise ValueError(f"image has {c} channels, model expects {self.in_channels}")
         if h % self.patch or w % self.patch or h <= 0 or w <= 0:
             raise ValueError(f"image size {h}x{w} must be positive multiples of {self.patch}")
-        if h > self.canvas or w > self.canvas:
-            raise ValueError(f"image size {h}x{w} exceeds the {self.canvas}x{self.canvas} canvas")
+        ch, cw = self.canvas_hw
+        if h > ch or w > cw:
+            raise ValueError(f"image size {h}x{w} exceeds the {ch}x{cw} canvas")
 
     def to_dict(self) -> dict:
         return asdict(self)
@@ -87,8 +104,15 @@ class Dims:
             raise ValueError("decoder.cross_attend=false has no encoder input; not an OCR model")
         if not config.get("glu", True):
             raise ValueError("glu=false (plain GELU FFN) is not built; the shipped config uses glu: true")
+        embed = config.get("embed", "hybrid" if "img_size" not in config else "patch")
+        if embed not in ("patch", "hybrid"):
+            raise ValueError("embed must be 'patch' or 'hybrid'")
+        size = config.get("img_size", HYBRID_CANVAS if embed == "hybrid" else 672)
+        ch, cw = (size, 0) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        if embed == "hybrid" and int(config.get("in_channels", enc.get("n_channels", 1))) != 1:
+            raise ValueError("the hybrid ResNetV2 embedder is single-channel (encoder.py:177-180)")
         return Dims(
-            canvas=int(config.get("img_size", 672)),
+            canvas=int(ch), canvas_w=int(cw) if cw != ch else 0, embed=embed,
             in_channels=int(config.get("in_channels", enc.get("n_channels", 1))),
             embed_dim=int(enc["embed_dim"]),
             enc_heads=int(enc["heads"]), enc_layers=int(enc["num_layers"]),
@@ -99,6 +123,17 @@ class Dims:
             pad=int(config.get("trg_pad_idx", 999)),
             patch=int(config.get("patch_size", PATCH)),
         )
+
+
+def reference_config(**over) -> dict:
+    """config/config.yml as create_model(config) consumes it: hybrid ResNetV2 embedder, 1 channel,
+    (160, 1008) canvas -- what every trained TeXOCR checkpoint uses."""
+    cfg = default_config(**over)
+    for k in ("img_size", "in_channels", "embed"):
+        if k not in over:
+            cfg.pop(k, None)
+    cfg.setdefault("embed", "hybrid")
+    return cfg
 
 
 def default_config(**over) -> dict:
@@ -112,7 +147,7 @@ def default_config(**over) -> dict:
         "decoder": {"embed_dim": 256, "heads": 8, "num_layers": 4, "cross_attend": True,
                     "exp_factor": 4, "dropout": 0.1},
         "max_length": 256, "vocab_size": 1000,
-        "img_size": 672, "in_channels": 3,
+        "img_size": 672, "in_channels": 3, "embed": "patch",
     }
     for k, v in over.items():
         if isinstance(v, dict) and isinstance(cfg.get(k), dict):

@@ -90,6 +90,26 @@ __device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 // ds_read_b128 fragment read (16 rows x one piece per lane group) is bank-conflict free.
 __device__ inline int swz128(int row, int piece) { return row * 128 + ((piece ^ (row & 7)) << 4); }
 
+// Division by a launch-time constant without an integer divide (the conv loaders split a GEMM row / k index
+// into (image, oh, ow) / (kh, kw, ic) for every 16-byte load): q = (umulhi(n, m) + n) >> l, exact for n < 2^31.
+struct FastDiv {
+    uint32_t d, m, l;
+    FastDiv() : d(1), m(1), l(0) {}
+    explicit FastDiv(uint32_t div) : d(div) {
+        l = 0;
+        while ((1u << l) < div) ++l;
+        m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - div)) / div + 1);
+    }
+    __host__ __device__ inline uint32_t div(uint32_t n) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)(((uint64_t)__umulhi(n, m) + n) >> l);
+#else
+        return (uint32_t)(((((uint64_t)n * m) >> 32) + n) >> l);
+#endif
+    }
+    __host__ __device__ inline void divmod(uint32_t n, uint32_t& q, uint32_t& r) const { q = div(n); r = n - q * d; }
+};
+
 __device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "common.h"
+#include "conv.h"
 #include "dec_attn.h"
 #include "dec_gemm.h"
 #include "enc_attn.h"
@@ -96,6 +97,12 @@ struct Engine : EngineBase {
     struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr; };
     struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr; };
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
+    // hybrid ResNetV2 embedder: standardised conv weights as [oc][kh][kw][ic] of T, GroupNorm affine fp32
+    struct GnW { float* g = nullptr; float* b = nullptr; };
+    struct BlockW { T *c1 = nullptr, *c2 = nullptr, *c3 = nullptr, *ds = nullptr; GnW n1, n2, n3, nds; int cin, mid, cout, stride; bool has_ds; };
+    T* stem_w = nullptr; GnW stem_gn; std::vector<BlockW> blocks;
+    T* act[4] = {nullptr, nullptr, nullptr, nullptr}; float *gn_partial = nullptr, *gn_stats = nullptr;
+    bool hybrid = false;
     float *enc_g = nullptr, *enc_b = nullptr, *encn_g = nullptr, *encn_b = nullptr;
     std::vector<AttnW> enc_attn; std::vector<MlpW> enc_mlp;
     float *tok_emb = nullptr, *pos_emb = nullptr, *dec_g = nullptr, *dec_b = nullptr, *decn_g = nullptr, *decn_b = nullptr;
@@ -225,17 +232,89 @@ struct Engine : EngineBase {
         return upload_f32(&w->b2, b2->data);
     }
 
+    // StdConv2d weight standardisation (resnet.py:58-61): per output channel over (ic, kh, kw), biased variance,
+    // eps 1e-6 inside the sqrt (F.batch_norm, training=True).  Input-independent, so folded at load time; the result
+    // is stored [oc][kh][kw][ic] (K order of the implicit-GEMM loader).  kpad > 0 pads K with zeros (stem: 49 -> 64).
+    int upload_conv(T** dst, const HostTensor& w, int kpad) {
+        const int oc = (int)w.shape[0], ic = (int)w.shape[1], kh = (int)w.shape[2], kw = (int)w.shape[3];
+        const int k = ic * kh * kw, kk = kpad > 0 ? kpad : k;
+        std::vector<float> o((size_t)oc * kk, 0.f);
+        for (int n = 0; n < oc; ++n) {
+            const float* src = &w.data[(size_t)n * k];
+            double m = 0, v = 0;
+            for (int i = 0; i < k; ++i) m += src[i];
+            m /= k;
+            for (int i = 0; i < k; ++i) v += (src[i] - m) * (src[i] - m);
+            const double rs = 1.0 / std::sqrt(v / k + 1e-6);
+            for (int c2 = 0; c2 < ic; ++c2)
+                for (int y = 0; y < kh; ++y)
+                    for (int x = 0; x < kw; ++x)
+                        o[(size_t)n * kk + ((size_t)y * kw + x) * ic + c2] = (float)((src[((size_t)c2 * kh + y) * kw + x] - m) * rs);
+        }
+        return upload_T(dst, o);
+    }
+    int load_gn(const std::string& p, int ch, GnW* g) {
+        const HostTensor *w = get(p + ".weight", {ch}), *b = get(p + ".bias", {ch});
+        if (!w || !b) return TXO_E_STATE;
+        if (int r = upload_f32(&g->g, w->data)) return r;
+        return upload_f32(&g->b, b->data);
+    }
+    int load_backbone(const std::string& p) {
+        const HostTensor* t;
+        if (!(t = get(p + ".stem.0.weight", {64, 1, 7, 7}))) return TXO_E_STATE;
+        if (int r = upload_conv(&stem_w, *t, 64)) return r;
+        if (int r = load_gn(p + ".stem.1", 64, &stem_gn)) return r;
+        static const int depths[3] = {2, 4, 6}, chans[3] = {256, 512, 1024};
+        int prev = 64;
+        for (int st = 0; st < 3; ++st)
+            for (int i = 0; i < depths[st]; ++i) {
+                BlockW b{};
+                b.cin = prev; b.cout = chans[st]; b.mid = chans[st] / 4; b.stride = (i == 0 && st > 0) ? 2 : 1; b.has_ds = i == 0;
+                const std::string q = p + ".stages." + std::to_string(st) + ".stage_blocks." + std::to_string(i);
+                // every layer is registered twice (block_list.N and block.N, resnet.py:132-141); if both are given they must agree
+                for (int j = 0; j < 6; ++j)
+                    for (const char* leaf : {".weight", ".bias"}) {
+                        auto a = host.find(q + ".block_list." + std::to_string(j) + leaf), c2 = host.find(q + ".block." + std::to_string(j) + leaf);
+                        if (a != host.end() && c2 != host.end() && a->second.data != c2->second.data)
+                            return fail(TXO_E_INVALID, q + ".block." + std::to_string(j) + leaf + " differs from its block_list alias");
+                    }
+                if (b.has_ds) {
+                    if (!(t = get(q + ".downsample.conv.weight", {b.cout, b.cin, 1, 1}))) return TXO_E_STATE;
+                    if (int r = upload_conv(&b.ds, *t, 0)) return r;
+                    if (int r = load_gn(q + ".downsample.norm", b.cout, &b.nds)) return r;
+                }
+                if (!(t = get(q + ".block_list.0.weight", {b.mid, b.cin, 1, 1}))) return TXO_E_STATE;
+                if (int r = upload_conv(&b.c1, *t, 0)) return r;
+                if (int r = load_gn(q + ".block_list.1", b.mid, &b.n1)) return r;
+                if (!(t = get(q + ".block_list.2.weight", {b.mid, b.mid, 3, 3}))) return TXO_E_STATE;
+                if (int r = upload_conv(&b.c2, *t, 0)) return r;
+                if (int r = load_gn(q + ".block_list.3", b.mid, &b.n2)) return r;
+                if (!(t = get(q + ".block_list.4.weight", {b.cout, b.mid, 1, 1}))) return TXO_E_STATE;
+                if (int r = upload_conv(&b.c3, *t, 0)) return r;
+                if (int r = load_gn(q + ".block_list.5", b.cout, &b.n3)) return r;
+                blocks.push_back(b);
+                prev = b.cout;
+            }
+        return 0;
+    }
+
     int finalize() override {
         if (ready) return fail(TXO_E_STATE, "weights already finalized");
         const txo_config& c = cfg;
-        const int G = c.canvas / 16;
+        const int npos = 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
         const HostTensor *t;
         if (!(t = get("encoder.cls_token", {1, 1, D}))) return TXO_E_STATE;
         if (int r = upload_f32(&cls, t->data)) return r;
-        if (!(t = get("encoder.pos_embed", {1, 1 + G * G, D}))) return TXO_E_STATE;
+        if (!(t = get("encoder.pos_embed", {1, npos, D}))) return TXO_E_STATE;
         if (int r = upload_f32(&pos, t->data)) return r;
-        if (!(t = get("encoder.patch_embed.proj.weight", {D, c.in_channels, 16, 16}))) return TXO_E_STATE;
-        if (int r = upload_T(&patch_w, t->data)) return r;
+        if (!hybrid) {
+            if (!(t = get("encoder.patch_embed.proj.weight", {D, c.in_channels, 16, 16}))) return TXO_E_STATE;
+            if (int r = upload_T(&patch_w, t->data)) return r;
+        } else {
+            if (int r = load_backbone("encoder.patch_embed.backbone_net")) return r;
+            if (!(t = get("encoder.patch_embed.proj.weight", {D, 1024, 1, 1}))) return TXO_E_STATE;
+            if (int r = upload_T(&patch_w, t->data)) return r;
+        }
         if (!(t = get("encoder.patch_embed.proj.bias", {D}))) return TXO_E_STATE;
         if (int r = upload_f32(&patch_b, t->data)) return r;
         if (int r = shared_ln("encoder.attn_layers", 2 * c.enc_layers, &enc_g, &enc_b)) return r;
@@ -281,10 +360,17 @@ struct Engine : EngineBase {
         const txo_config& c = cfg;
         D = c.embed_dim; Ie = c.enc_heads * DH; Id = c.dec_heads * DH; Fe = c.enc_exp * D; Fd = c.dec_exp * D;
         V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
-        const int G = c.canvas / 16;
-        Nmax = c.max_tokens > 0 ? c.max_tokens : 1 + G * G;
+        hybrid = c.embed == TXO_EMBED_HYBRID;
+        Nmax = c.max_tokens > 0 ? c.max_tokens : 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
         const size_t M = (size_t)Bmax * Nmax;
         const int Imax = Ie > Id ? Ie : Id, Fmax = Fe > Fd ? Fe : Fd;
+        if (hybrid) {
+            // largest NHWC activation per image: stem output (H/2 x W/2 x 64) = stage-0 output (H/4 x W/4 x 256) = 4096 per token
+            const size_t E = (size_t)Bmax * (Nmax - 1) * 4096;
+            for (auto& a : act) if (int r = dalloc(&a, E)) return r;
+            if (int r = dalloc(&gn_partial, (size_t)Bmax * 64 * 64)) return r;
+            if (int r = dalloc(&gn_stats, (size_t)Bmax * 64)) return r;
+        }
         if (int r = dalloc(&ex, M * D)) return r;
         if (int r = dalloc(&ey, M * D)) return r;
         if (int r = dalloc(&ez, M * D)) return r;
@@ -327,21 +413,84 @@ struct Engine : EngineBase {
         else hipLaunchKernelGGL((ln_rows_generic_kernel<TZ, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, D);
     }
 
+    // ---- hybrid embedder: ResNetV2 [2,4,6] on NHWC activations (conv.h) -----------------------------------------
+    static void same_pad(int in, int k, int stride, int* out, int* pad_lo) {   // utils.py:97-99,112-123 (TF "SAME")
+        *out = (in + stride - 1) / stride;
+        const int pad = std::max((*out - 1) * stride + (k - 1) + 1 - in, 0);
+        *pad_lo = pad / 2;
+    }
+    void conv(hipStream_t s, const T* in, const T* w, T* out, int B, int H, int W, int C, int OC, int k, int stride) {
+        int OH, OW, pt, pl;
+        same_pad(H, k, stride, &OH, &pt); same_pad(W, k, stride, &OW, &pl);
+        LoadConv<T> ld{in, H, W, C, stride, pt, pl, FastDiv(OH * OW), FastDiv(OW), FastDiv(C), FastDiv(k)};
+        launch_gemm_big<T>(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<T>{out, OC, nullptr});
+    }
+    template <bool RELU, bool RES>
+    void group_norm(hipStream_t s, const T* x, const T* res, T* y, const GnW& g, int B, int HW, int C) {
+        const int chunk_px = std::max(256, (HW + 63) / 64), nchunk = (HW + chunk_px - 1) / chunk_px;
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(nchunk, B), dim3(256), 0, s, x, gn_partial, HW, C, chunk_px);
+        hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(32), 0, s, gn_partial, gn_stats, nchunk, (double)HW * (C / 32));
+        const size_t nvec = (size_t)B * HW * C / Elem<T>::PER16;
+        hipLaunchKernelGGL((gn_apply_kernel<T, RELU, RES>), dim3((nvec + 255) / 256), dim3(256), 0, s, x, res, y, gn_stats, g.g,
+                           g.b, HW, C, nvec);
+    }
+    int backbone(const float* img, int B, int H, int W, const T** feat, hipStream_t s) {
+        int h1, w1, pt, pl;
+        same_pad(H, 7, 2, &h1, &pt); same_pad(W, 7, 2, &w1, &pl);
+        launch_gemm_big<T>(s, LoadStem<T>{img, H, W, pt, pl, FastDiv(h1 * w1), FastDiv(w1)}, stem_w, B * h1 * w1, 64, 64,
+                           EpiStore<T>{act[1], 64, nullptr});
+        group_norm<true, false>(s, act[1], nullptr, act[1], stem_gn, B, h1 * w1, 64);
+        int hc, wc, ppt, ppl;
+        same_pad(h1, 3, 2, &hc, &ppt); same_pad(w1, 3, 2, &wc, &ppl);
+        {
+            const size_t nvec = (size_t)B * hc * wc * 64 / Elem<T>::PER16;
+            hipLaunchKernelGGL((maxpool3x3s2_kernel<T>), dim3((nvec + 255) / 256), dim3(256), 0, s, act[1], act[0], h1, w1, 64,
+                               hc, wc, ppt, ppl, nvec);
+        }
+        T* cur = act[0];
+        for (const BlockW& b : blocks) {                      // Bottleneck.forward (resnet.py:143-149)
+            const int ho = (hc + b.stride - 1) / b.stride, wo = (wc + b.stride - 1) / b.stride;
+            const T* res = cur;
+            if (b.has_ds) {                                   // DownSample: 1x1 stride-s StdConv + GroupNorm (no act)
+                conv(s, cur, b.ds, act[1], B, hc, wc, b.cin, b.cout, 1, b.stride);
+                group_norm<false, false>(s, act[1], nullptr, act[1], b.nds, B, ho * wo, b.cout);
+                res = act[1];
+            }
+            conv(s, cur, b.c1, act[2], B, hc, wc, b.cin, b.mid, 1, 1);
+            group_norm<true, false>(s, act[2], nullptr, act[2], b.n1, B, hc * wc, b.mid);
+            conv(s, act[2], b.c2, act[3], B, hc, wc, b.mid, b.mid, 3, b.stride);
+            group_norm<true, false>(s, act[3], nullptr, act[3], b.n2, B, ho * wo, b.mid);
+            conv(s, act[3], b.c3, act[2], B, ho, wo, b.mid, b.cout, 1, 1);
+            group_norm<true, true>(s, act[2], res, act[0], b.n3, B, ho * wo, b.cout);   // relu(norm(x) + res)
+            cur = act[0]; hc = ho; wc = wo;
+        }
+        if (hc != H / 16 || wc != W / 16) return fail(TXO_E_INVALID, "backbone output grid does not match H/16 x W/16");
+        *feat = cur;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
     int encode(const float* img, int B, int C, int H, int W, float* enc_out, hipStream_t s) override {
         if (!ready) return fail(TXO_E_STATE, "weights not finalized");
         if (C != cfg.in_channels) return fail(TXO_E_INVALID, "image channel count does not match in_channels");
         if (H <= 0 || W <= 0 || H % 16 || W % 16) return fail(TXO_E_INVALID, "image height/width must be positive multiples of 16");
-        if (H > cfg.canvas || W > cfg.canvas) return fail(TXO_E_INVALID, "image larger than the position-embedding canvas");
+        if (H > cfg.canvas_h || W > cfg.canvas_w) return fail(TXO_E_INVALID, "image larger than the position-embedding canvas");
         const int h = H / 16, w = W / 16, hw = h * w, N = hw + 1;
         if (B < 1 || B > Bmax) return fail(TXO_E_INVALID, "batch exceeds engine max_batch");
         if (N > Nmax) return fail(TXO_E_INVALID, "token count exceeds engine max_tokens");
-        const int M = B * N, G = cfg.canvas / 16;
+        const int M = B * N, G = cfg.canvas_w / 16;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
 
         hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, ex, cls, pos, B, N, D);
-        launch_gemm_big<T>(s, LoadPatch<T>{img, C, H, W, hw, w}, patch_w, B * hw, D, C * 256,
-                           EpiPatch{ex, patch_b, pos, D, hw, w, G});
+        if (!hybrid) {
+            launch_gemm_big<T>(s, LoadPatch<T>{img, C, H, W, hw, w}, patch_w, B * hw, D, C * 256,
+                               EpiPatch{ex, patch_b, pos, D, hw, w, G});
+        } else {
+            const T* feat = nullptr;
+            if (int r = backbone(img, B, H, W, &feat, s)) return r;
+            launch_gemm_big<T>(s, LoadPlain<T>{feat, 1024}, patch_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
+        }
         const size_t hs = (size_t)M * Ie;      // one of q/k/v, head-major [B*heads][N][64]
         for (int l = 0; l < cfg.enc_layers; ++l) {
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
@@ -643,7 +792,11 @@ struct Engine : EngineBase {
 };
 
 static int validate(const txo_config& c) {
-    if (c.canvas <= 0 || c.canvas % 16) return fail(TXO_E_INVALID, "canvas must be a positive multiple of 16");
+    if (c.canvas_h <= 0 || c.canvas_h % 16 || c.canvas_w <= 0 || c.canvas_w % 16)
+        return fail(TXO_E_INVALID, "canvas height/width must be positive multiples of 16");
+    if (c.embed != TXO_EMBED_PATCH && c.embed != TXO_EMBED_HYBRID) return fail(TXO_E_INVALID, "embed must be TXO_EMBED_PATCH or TXO_EMBED_HYBRID");
+    if (c.embed == TXO_EMBED_HYBRID && c.in_channels != 1)
+        return fail(TXO_E_INVALID, "the hybrid ResNetV2 embedder takes single-channel images");
     if (c.embed_dim < 64 || c.embed_dim % 64 || c.embed_dim > 768)
         return fail(TXO_E_INVALID, "embed_dim must be a multiple of 64 in [64, 768]");
     if (c.enc_heads < 1 || c.dec_heads < 1 || c.enc_layers < 1 || c.dec_layers < 1)
@@ -653,8 +806,8 @@ static int validate(const txo_config& c) {
     if (c.in_channels < 1 || c.vocab < 2 || c.max_len < 1) return fail(TXO_E_INVALID, "bad in_channels / vocab / max_len");
     if (c.bos < 0 || c.bos >= c.vocab) return fail(TXO_E_INVALID, "bos token outside the vocabulary");
     if (c.max_batch < 1 || c.max_batch > 65535) return fail(TXO_E_INVALID, "max_batch must be in [1, 65535]");
-    const int G = c.canvas / 16;
-    if (c.max_tokens < 0 || c.max_tokens > 1 + G * G) return fail(TXO_E_INVALID, "max_tokens exceeds 1 + (canvas/16)^2");
+    if (c.max_tokens < 0 || c.max_tokens > 1 + (c.canvas_h / 16) * (c.canvas_w / 16))
+        return fail(TXO_E_INVALID, "max_tokens exceeds 1 + canvas_h*canvas_w/256");
     if (c.dtype != TXO_F32 && c.dtype != TXO_BF16) return fail(TXO_E_INVALID, "dtype must be TXO_F32 or TXO_BF16");
     return 0;
 }

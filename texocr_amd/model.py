@@ -66,8 +66,10 @@ class HipEngine:
             raise RuntimeError("no GPU visible: the texocr_amd engine runs only on an MI355X (no CPU fallback)")
         self.dims, self.dtype = dims, dtype
         self.max_batch, self.max_tokens = max_batch, max_tokens or dims.n_pos
+        ch, cw = dims.canvas_hw
         cfg = _lib.TxoConfig(
-            canvas=dims.canvas, in_channels=dims.in_channels, embed_dim=dims.embed_dim,
+            canvas_h=ch, canvas_w=cw, embed=1 if dims.embed == "hybrid" else 0,
+            in_channels=dims.in_channels, embed_dim=dims.embed_dim,
             enc_heads=dims.enc_heads, enc_layers=dims.enc_layers, dec_heads=dims.dec_heads,
             dec_layers=dims.dec_layers, enc_exp=dims.enc_exp, dec_exp=dims.dec_exp, vocab=dims.vocab,
             max_len=dims.max_len, bos=dims.bos, eos=dims.eos, pad=dims.pad, dtype=_DTYPES[dtype],
@@ -182,7 +184,7 @@ class VisionEncoder:
     def __init__(self, engine: HipEngine):
         self._engine = engine
         d = engine.dims
-        self.height = self.width = d.canvas
+        self.height, self.width = d.canvas_hw
         self.patch_size = d.patch
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

@@ -19,7 +19,7 @@ from typing import Dict, List, Tuple
 
 import numpy as np
 
-from .config import Dims
+from .config import Dims, RESNET_CHANNELS, RESNET_DEPTHS
 
 Shape = Tuple[int, ...]
 
@@ -52,6 +52,38 @@ def _stack_keys(prefix: str, kinds: List[str], D: int, inner: int, ffn: int) -> 
     return out
 
 
+def resnet_blocks():
+    """(stage, block, in_ch, mid_ch, out_ch, stride, has_downsample) for ResNetV2 [2,4,6] (resnet.py:152-254)."""
+    out, prev = [], 64
+    for s, (depth, ch) in enumerate(zip(RESNET_DEPTHS, RESNET_CHANNELS)):
+        for i in range(depth):
+            out.append((s, i, prev, ch // 4, ch, (2 if s > 0 else 1) if i == 0 else 1, i == 0))
+            prev = ch
+    return out
+
+
+def _resnet_keys(p: str) -> List[Tuple[str, Shape, str]]:
+    """ResNetV2 state_dict keys.  Every Bottleneck registers its six layers twice (`block_list.N` and the
+    nn.Sequential `block.N` built from the same modules, resnet.py:132-141): aliased keys, one storage."""
+    keys: List[Tuple[str, Shape, str]] = [
+        (f"{p}.stem.0.weight", (64, 1, 7, 7), f"{p}.stem.0.weight"),
+        (f"{p}.stem.1.weight", (64,), f"{p}.stem.1.weight"), (f"{p}.stem.1.bias", (64,), f"{p}.stem.1.bias")]
+    for s, i, cin, mid, cout, stride, ds in resnet_blocks():
+        b = f"{p}.stages.{s}.stage_blocks.{i}"
+        if ds:
+            keys += [(f"{b}.downsample.conv.weight", (cout, cin, 1, 1), f"{b}.downsample.conv.weight"),
+                     (f"{b}.downsample.norm.weight", (cout,), f"{b}.downsample.norm.weight"),
+                     (f"{b}.downsample.norm.bias", (cout,), f"{b}.downsample.norm.bias")]
+        shapes = [(mid, cin, 1, 1), (mid,), (mid, mid, 3, 3), (mid,), (cout, mid, 1, 1), (cout,)]
+        for alias in ("block_list", "block"):
+            for j, shp in enumerate(shapes):
+                canon = f"{b}.block_list.{j}"
+                keys.append((f"{b}.{alias}.{j}.weight", shp, f"{canon}.weight"))
+                if j % 2 == 1:
+                    keys.append((f"{b}.{alias}.{j}.bias", shp, f"{canon}.bias"))
+    return keys
+
+
 def state_dict_layout(d: Dims) -> List[Tuple[str, Shape, str]]:
     """Every key of the reference OCRModel.state_dict() for these dims, with its shape and
     the canonical (de-aliased) key that owns the storage."""
@@ -59,9 +91,14 @@ def state_dict_layout(d: Dims) -> List[Tuple[str, Shape, str]]:
     keys: List[Tuple[str, Shape, str]] = [
         ("encoder.cls_token", (1, 1, D), "encoder.cls_token"),
         ("encoder.pos_embed", (1, d.n_pos, D), "encoder.pos_embed"),
-        ("encoder.patch_embed.proj.weight", (D, d.in_channels, d.patch, d.patch), "encoder.patch_embed.proj.weight"),
-        ("encoder.patch_embed.proj.bias", (D,), "encoder.patch_embed.proj.bias"),
     ]
+    if d.embed == "hybrid":
+        keys += _resnet_keys("encoder.patch_embed.backbone_net")
+        keys += [("encoder.patch_embed.proj.weight", (D, RESNET_CHANNELS[-1], 1, 1), "encoder.patch_embed.proj.weight"),
+                 ("encoder.patch_embed.proj.bias", (D,), "encoder.patch_embed.proj.bias")]
+    else:
+        keys += [("encoder.patch_embed.proj.weight", (D, d.in_channels, d.patch, d.patch), "encoder.patch_embed.proj.weight"),
+                 ("encoder.patch_embed.proj.bias", (D,), "encoder.patch_embed.proj.bias")]
     keys += _stack_keys("encoder.attn_layers", enc_kinds(d), D, d.enc_inner, d.enc_ffn)
     keys += [("encoder.norm.weight", (D,), "encoder.norm.weight"),
              ("encoder.norm.bias", (D,), "encoder.norm.bias"),
@@ -76,7 +113,7 @@ def state_dict_layout(d: Dims) -> List[Tuple[str, Shape, str]]:
     return keys
 
 
-_LN_KEY = re.compile(r"(layers\.\d+\.0|\.norm)\.(weight|bias)$")
+_LN_KEY = re.compile(r"(layers\.\d+\.0|\.norm|backbone_net\.stem\.1|\.block_list\.[135])\.(weight|bias)$")
 
 
 def _draw(key: str, shape: Shape, seed: int) -> np.ndarray:
