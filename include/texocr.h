@@ -98,6 +98,12 @@ int txo_generate_from_enc(txo_engine* e, const float* enc_dev, int32_t B, int32_
                           int32_t eos, int64_t* tokens_out_dev, int32_t* n_steps_out, float* logits_out_dev,
                           void* stream);
 
+/* Token selection for the following decode steps / generate calls.  mode 0 (default): greedy argmax.  mode 1:
+ * the reference's sampler (decoder.py:104-108 + utils.topk, utils.py:85-91): keep the `topk` largest logits
+ * (the reference uses int((1 - 0.9) * vocab) = 99 for vocab 1000), softmax(logits / temp), one multinomial draw,
+ * from a counter-based RNG keyed by `seed` (reproducible; a different stream than torch.multinomial). */
+int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed);
+
 /* Timing hooks for bench.py: average duration (ms) of the decode-step cross-attention launches and of
  * the encoder launches recorded with HIP events on the stream the kernels run on, since the last
  * txo_profile_reset; *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,

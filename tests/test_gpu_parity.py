@@ -319,21 +319,43 @@ def test_errors_and_state_dict_checks():
     assert out.shape == (2, 8)
 
 
-def test_sampling_mode_support_and_reproducibility():
+def test_sampling_mode_support_reproducibility_and_distribution():
+    """N2: the reference's sampler (top-k 99 -> softmax(/0.3) -> multinomial, decoder.py:104-108) on the device.
+    A different RNG stream than torch.multinomial, so parity is statistical: support, reproducibility, and a
+    chi-square test of 4096 first-step draws against the oracle's sampling distribution."""
+    cpu_ref = _oracle()
     d = Dims(canvas=224)
-    d, sd, m = build(d, seed=0, max_batch=2)
-    img = torch.from_numpy(synth.synth_images(2, 3, 64, 64, seed=2)).cuda()
-    g1 = torch.Generator(device="cuda").manual_seed(7)
-    a = m.generate(img, 12, temp=0.3, decode="sample", generator=g1)
-    g2 = torch.Generator(device="cuda").manual_seed(7)
-    b = m.generate(img, 12, temp=0.3, decode="sample", generator=g2)
-    assert torch.equal(a, b) and a.shape == (2, 12)
+    d, sd, m = build(d, seed=0, max_batch=64)
+    img1 = torch.from_numpy(synth.synth_images(1, 3, 64, 64, seed=2))
+    img = img1.cuda().expand(2, -1, -1, -1).contiguous()
+    a = m.generate(img, 12, temp=0.3, decode="sample", seed=7)
+    b = m.generate(img, 12, temp=0.3, decode="sample", seed=7)
+    c = m.generate(img, 12, temp=0.3, decode="sample", seed=8)
+    assert torch.equal(a, b) and a.shape == (2, 12) and not torch.equal(a, c)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    assert torch.equal(m.generate(img, 12, temp=0.3, decode="sample", generator=g), a)
     # every sampled token lies in the reference's top-k support (k = int(0.1 * 1000) = 99, utils.py:85-91)
     enc = m.encoder(img)
     prefix = torch.cat([torch.full((2, 1), d.bos, dtype=torch.long, device="cuda"), a[:, :-1]], 1)
     logits = m.decoder.net(prefix, enc=enc)
     top = logits.topk(99, dim=-1).indices
     assert bool((top == a[:, :, None]).any(-1).all())
+    # temperature -> 0 degenerates to greedy
+    assert torch.equal(m.generate(img, 12, temp=1e-4, decode="sample", seed=3), m.generate(img, 12))
+    # distribution of the first token: 64 identical rows x 64 seeds, temp 1.0 to spread the mass
+    big = img1.cuda().expand(64, -1, -1, -1).contiguous()
+    draws = torch.cat([m.generate(big, 1, temp=1.0, decode="sample", seed=1000 + s)[:, 0] for s in range(64)]).cpu()
+    step0 = cpu_ref.generate_cached(cpu_ref.to_torch_sd(sd), img1, d.bos, d.eos, 1, collect_logits=True)[1][:, 0]
+    probs = cpu_ref.sample_probs(step0, 1.0)[0].double()
+    assert int((probs > 0).sum()) == 99
+    n = draws.numel()
+    counts = torch.bincount(draws, minlength=d.vocab).double()
+    assert float(counts[probs == 0].sum()) == 0                      # nothing outside the support
+    exp = probs * n
+    keep = exp >= 5
+    chi = float((((counts - exp) ** 2 / exp)[keep]).sum() + (counts[~keep].sum() - exp[~keep].sum()) ** 2 / max(float(exp[~keep].sum()), 1e-9))
+    dof = int(keep.sum())
+    assert chi < dof + 6 * (2 * dof) ** 0.5, (chi, dof)             # ~6 sigma of the chi-square law
 
 
 def test_world1_rccl_allgather_smoke():

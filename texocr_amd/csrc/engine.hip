@@ -57,6 +57,7 @@ struct EngineBase {
     virtual int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) = 0;
     virtual int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                          int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) = 0;
+    int sample_mode = 0, sample_topk = 0; float sample_temp = 1.f; unsigned long long sample_seed = 0;
     virtual int profile_enable(int on) = 0;
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
 };
@@ -664,8 +665,10 @@ struct Engine : EngineBase {
         dbg(s, "logits");
         StepArgs sa{llog, V, nb, cur_tok + r0, tokens_out ? tokens_out + r0 * out_stride : nullptr, out_stride,
                     logits_out ? logits_out + r0 * (size_t)out_stride * V : nullptr, st + li, eos_seen + r0,
-                    done_flag + (size_t)li * Tmax, eos};
-        hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
+                    done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp,
+                    sample_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)r0};
+        if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(nb), dim3(64), (size_t)V * sizeof(float), s, sa);
+        else hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
         dbg(s, "argmax");
         if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
         return 0;
@@ -719,7 +722,7 @@ struct Engine : EngineBase {
         // Measured on MI355X (B=64, 224x672, T=256): the step is bound by the GPU-side latency chain of its ~26
         // dependent launches, not by the host -- graph replay and 2-4 lanes give the same wall time as eager
         // single-stream launches (57.1 vs 58.0 / 58.2 ms) -- so both stay opt-in: TXO_GRAPH=1, TXO_LANES=n.
-        const bool eager = logits_out != nullptr || g_dbg || getenv("TXO_GRAPH") == nullptr;
+        const bool eager = logits_out != nullptr || g_dbg || sample_mode || getenv("TXO_GRAPH") == nullptr;
         int want = 1;
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
@@ -877,6 +880,14 @@ int txo_generate_from_enc(txo_engine* e, const float* enc, int32_t B, int32_t N,
                           int64_t* tokens_out, int32_t* n_steps, float* logits_out, void* stream) {
     if (!e || !enc || !tokens_out) return fail(TXO_E_INVALID, "null argument");
     return e->impl->generate(nullptr, enc, B, 0, 0, 0, N, max_len, eos, tokens_out, n_steps, logits_out, (hipStream_t)stream);
+}
+
+int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed) {
+    if (!e) return fail(TXO_E_INVALID, "null engine");
+    if (mode != 0 && mode != 1) return fail(TXO_E_INVALID, "sampling mode must be 0 (greedy) or 1 (top-k / temperature / multinomial)");
+    if (mode == 1 && (topk < 1 || !(temp > 0.f))) return fail(TXO_E_INVALID, "sampling needs topk >= 1 and temp > 0");
+    e->impl->sample_mode = mode; e->impl->sample_topk = topk; e->impl->sample_temp = mode ? temp : 1.f; e->impl->sample_seed = seed;
+    return 0;
 }
 
 int txo_profile_enable(txo_engine* e, int32_t on) { return e ? e->impl->profile_enable(on) : fail(TXO_E_INVALID, "null engine"); }

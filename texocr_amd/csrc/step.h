@@ -28,7 +28,25 @@ struct StepArgs {
     int out_stride;
     float* logits_out;          // [rows][out_stride][V] or null
     StepState* st; int* eos_seen; int* done_flag; int eos;   // eos < 0: no eos check
+    // sampling (reference decoder.py:104-108): keep the topk largest logits, softmax(logits / temp), draw one
+    int topk; float inv_temp; unsigned long long seed;
 };
+
+// append the chosen token, update the GLOBAL eos bookkeeping, advance the device-side position (lane 0 of a row)
+__device__ inline void commit_token(const StepArgs& a, int row, int t, int tok) {
+    a.cur_tok[row] = tok;
+    if (a.tokens_out) a.tokens_out[(size_t)row * a.out_stride + t] = tok;
+    unsigned add = 1u;
+    if (a.eos >= 0 && tok == a.eos && !a.eos_seen[row]) { a.eos_seen[row] = 1; add += 1u << 16; }
+    const unsigned old = atomicAdd(&a.st->arrive, add);
+    if ((old & 0xffffu) == (unsigned)(a.rows - 1)) {          // last arriver: sole owner of the state now
+        const int total = a.st->rows_with_eos + (int)((old + add) >> 16);
+        a.st->rows_with_eos = total;
+        a.done_flag[t] = (a.eos >= 0 && total >= a.rows) ? 1 : 0;
+        a.st->arrive = 0u;
+        a.st->t = t + 1;
+    }
+}
 
 __global__ __launch_bounds__(64) void argmax_step_kernel(StepArgs a) {
     const int row = blockIdx.x, lane = threadIdx.x;
@@ -70,20 +88,99 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(StepArgs a) {
         const int oi = __shfl_xor(bi, o, 64);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }   // ties -> lowest index (torch.argmax)
     }
-    if (lane == 0) {
-        a.cur_tok[row] = bi;
-        if (a.tokens_out) a.tokens_out[(size_t)row * a.out_stride + t] = bi;
-        unsigned add = 1u;
-        if (a.eos >= 0 && bi == a.eos && !a.eos_seen[row]) { a.eos_seen[row] = 1; add += 1u << 16; }
-        const unsigned old = atomicAdd(&a.st->arrive, add);
-        if ((old & 0xffffu) == (unsigned)(a.rows - 1)) {          // last arriver: sole owner of the state now
-            const int total = a.st->rows_with_eos + (int)((old + add) >> 16);
-            a.st->rows_with_eos = total;
-            a.done_flag[t] = (a.eos >= 0 && total >= a.rows) ? 1 : 0;
-            a.st->arrive = 0u;
-            a.st->t = t + 1;
-        }
+    if (lane == 0) commit_token(a, row, t, bi);
+}
+
+// Philox4x32-10 (counter-based, no state to carry between steps): counter = (row, t, 0, 0), key = seed.
+__device__ inline void philox4x32(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+}
+__device__ inline unsigned fkey(float f) {          // order-preserving float -> uint
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// The reference sampler for one step (decoder.py:104-108, utils.py:85-91): top-k filter (k = int((1-0.9)*V)),
+// softmax(logits / temp), one multinomial draw.  One wave per row, the row staged in LDS.
+//   k-th largest: bitwise bisection on order-preserving uint keys (32 counting passes);
+//   draw: u ~ Philox -> inverse CDF over the kept entries in index order (lane-contiguous chunks + wave scan).
+// Statistically equivalent to torch.multinomial (a different RNG stream), reproducible for a given seed.
+__global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
+    extern __shared__ float row_lds[];
+    const int row = blockIdx.x, lane = threadIdx.x, V = a.V;
+    const int t = a.st->t;
+    const float* lg = a.logits + (size_t)row * V;
+    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
+    float mx = -3.4e38f;
+    for (int j = lane; j < V; j += 64) { const float v = lg[j]; row_lds[j] = v; if (lo) lo[j] = v; mx = fmaxf(mx, v); }
+    mx = wave_max(mx);
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // own LDS writes done (single wave)
+    // k-th largest key
+    const int k = min(max(a.topk, 1), V);
+    unsigned prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int cnt = 0;
+        for (int j = lane; j < V; j += 64) cnt += fkey(row_lds[j]) >= cand ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        if (cnt >= k) prefix = cand;
+    }
+    // kept set: keys > prefix, plus the first (k - n_greater) entries equal to it in index order (ties)
+    const int per = (V + 63) / 64, j0 = lane * per, j1 = min(V, j0 + per);
+    int ngt = 0, neq = 0;
+    for (int j = j0; j < j1; ++j) { const unsigned key = fkey(row_lds[j]); ngt += key > prefix; neq += key == prefix; }
+    int ngt_all = ngt, eq_before = neq;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ngt_all += __shfl_xor(ngt_all, o, 64);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(eq_before, o, 64); if (lane >= o) eq_before += v; }
+    eq_before -= neq;                                 // exclusive scan of the tie counts
+    int eq_left = (k - ngt_all) - eq_before;          // ties this lane may still keep
+    float psum = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const float v = row_lds[j];
+        const unsigned key = fkey(v);
+        bool keep = key > prefix;
+        if (key == prefix && eq_left > 0) { keep = true; --eq_left; }
+        const float p = keep ? expf((v - mx) * a.inv_temp) : 0.f;
+        row_lds[j] = p;                               // this lane owns [j0, j1)
+        psum += p;
+    }
+    float incl = psum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const float total = __shfl(incl, 63, 64);
+    unsigned c[4] = {(unsigned)row, (unsigned)t, 0u, 0u};
+    philox4x32(c, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+    const float u = ((c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);    // (0, 1)
+    const float target = u * total;
+    // the lane whose inclusive prefix first reaches the target holds the sample
+    const unsigned long long hit = __ballot(incl >= target && psum > 0.f);
+    const int owner = hit ? (int)__builtin_ctzll(hit) : 63;
+    int pick = -1;
+    if (lane == owner) {
+        float run = incl - psum;
+        for (int j = j0; j < j1; ++j) { const float p = row_lds[j]; if (p > 0.f) { pick = j; run += p; if (run >= target) break; } }
+    }
+    pick = __shfl(pick, owner, 64);
+    if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max
+        float best = -3.4e38f; int bi = 0x7fffffff;
+        for (int j = lane; j < V; j += 64) { const float v = lg[j]; if (v > best) { best = v; bi = j; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        pick = bi;
+    }
+    if (lane == 0) commit_token(a, row, t, pick);
 }
 
 // (re)start a decode: position 0, BOS everywhere; a BOS that equals eos already satisfies the check

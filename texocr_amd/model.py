@@ -165,6 +165,12 @@ class HipEngine:
         toks = toks[:, :n.value]
         return (toks, logits[:, :n.value]) if return_logits else toks
 
+    def set_sampling(self, on: bool, temp: float = 1.0, seed: int = 0, threshold: float = 0.9) -> None:
+        """on=True: the reference sampler (top-k with k = int((1 - threshold) * vocab), utils.py:85-91 -- 99 for
+        vocab 1000 because of float rounding -- then softmax(/temp) and one multinomial draw, decoder.py:104-108)."""
+        k = int((1 - threshold) * self.dims.vocab)
+        _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
+
     # profiling hooks used by bench.py
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.txo_profile_enable(self.handle, 1 if on else 0))
@@ -231,7 +237,8 @@ class AutoRegressiveDecoder:
 
     @torch.no_grad()
     def generate(self, start_tokens: torch.Tensor, eos_tok: Optional[int], max_len: int, temp: float = 1.0,
-                 decode: str = "greedy", generator: Optional[torch.Generator] = None, **kwargs) -> torch.Tensor:
+                 decode: str = "greedy", generator: Optional[torch.Generator] = None, seed: Optional[int] = None,
+                 **kwargs) -> torch.Tensor:
         enc = kwargs.pop("enc", None)
         mask = kwargs.pop("mask", None)
         if kwargs:
@@ -249,16 +256,23 @@ class AutoRegressiveDecoder:
             raise ValueError(f"start length {T0} + max_len {max_len} exceeds decoder.max_len {self.max_len}: the "
                              "reference would slide its window (decoder.py:99-100); the KV-cached engine refuses")
         eng = self._engine
-        fast = decode == "greedy" and T0 == 1 and bool((st == eng.dims.bos).all())
-        if fast:
-            out = eng.generate(None, max_len, eos_tok, enc=enc)
-        else:
-            out = self._generate_stepwise(st, eos_tok, max_len, temp, decode, generator, enc)
+        if decode == "sample":
+            if seed is None:
+                seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2**62, (1,)).item())
+            eng.set_sampling(True, temp=temp, seed=seed)
+        try:
+            if T0 == 1 and bool((st == eng.dims.bos).all()):
+                out = eng.generate(None, max_len, eos_tok, enc=enc)
+            else:
+                out = self._generate_stepwise(st, eos_tok, max_len, enc)
+        finally:
+            if decode == "sample":
+                eng.set_sampling(False)
         return out.squeeze(0) if squeeze else out
 
-    def _generate_stepwise(self, st, eos_tok, max_len, temp, decode, generator, enc):
-        """General form (arbitrary start prefix, or sampling): one engine step per position, the
-        reference's per-step host-side eos check (decoder.py:115-116)."""
+    def _generate_stepwise(self, st, eos_tok, max_len, enc):
+        """General form (arbitrary start prefix): one engine step per position with the reference's per-step
+        host-side eos check (decoder.py:115-116); the engine picks the token (argmax or its sampler)."""
         eng = self._engine
         st = st.to(enc.device)
         B, T0 = st.shape
@@ -268,14 +282,7 @@ class AutoRegressiveDecoder:
         tok = st[:, T0 - 1].contiguous()
         output = st
         for i in range(max_len):
-            logits, nxt = eng.decode_step(T0 - 1 + i, tok)
-            if decode == "sample":                                               # decoder.py:104-108
-                k = int((1 - 0.9) * logits.shape[-1])                            # utils.py:85-91 (99 for V=1000)
-                val, ind = torch.topk(logits, k)
-                filt = torch.full_like(logits, float("-inf")).scatter_(1, ind, val)
-                probs = torch.softmax(filt / temp, dim=-1)
-                nxt = torch.multinomial(probs, 1, generator=generator).squeeze(1)
-            tok = nxt
+            _, tok = eng.decode_step(T0 - 1 + i, tok, want_logits=False)
             output = torch.cat((output, tok[:, None]), dim=-1)
             if eos_tok is not None and bool((output == eos_tok).any(dim=1).all()):
                 break
@@ -309,7 +316,7 @@ class OCRModel:
 
     @torch.no_grad()
     def generate(self, src: torch.Tensor, max_len: int, temp: float = 0.3, *, decode: str = "greedy",
-                 generator: Optional[torch.Generator] = None, return_logits: bool = False):
+                 generator: Optional[torch.Generator] = None, seed: Optional[int] = None, return_logits: bool = False):
         if decode == "greedy" and self.bos_token == self._engine.dims.bos:
             if max_len > self.decoder.max_len:
                 raise ValueError(f"max_len {max_len} exceeds decoder.max_len {self.decoder.max_len}: the reference "
@@ -318,7 +325,7 @@ class OCRModel:
         enc = self.encoder(src)
         start = torch.full((src.shape[0], 1), self.bos_token, dtype=torch.int64, device=src.device)   # ocr_model.py:57
         return self.decoder.generate(start_tokens=start, eos_tok=self.eos_token, max_len=max_len, temp=temp,
-                                     decode=decode, generator=generator, enc=enc)
+                                     decode=decode, generator=generator, seed=seed, enc=enc)
 
     def forward(self, *a, **k):
         raise NotImplementedError("OCRModel.forward is the training loss (ocr_model.py:38-44); this engine "
