@@ -344,7 +344,27 @@ def cap_hybrid():
          tokens=toks.numpy().astype(np.int16), step_logits=step_logits.numpy(), margin=margins(step_logits))
 
 
-CAPS = {"hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
+def cap_tokenizer():
+    """N4: encode/decode vectors from the reference RegExTokenizer on its own vocabulary file (the data file itself
+    is copied to tests/golden/tokenizer_clean_1k.txt), and process_output (utils.py:73-79) known answers."""
+    import shutil
+    from TeXOCR.tokenizer.tokenizer import RegExTokenizer as RefTok
+    src = os.path.join(REF, "tokenizer", "tokenizer_clean_1k.txt")
+    shutil.copyfile(src, os.path.join(GOLD, "tokenizer_clean_1k.txt"))
+    ref = RefTok()
+    ref.load(src)
+    texts = [r"\int _ { 0 } ^ { 1 } x ^ 2 d x", r"\frac { \partial f } { \partial x } = \lambda \sum _ { i = 1 } ^ { n } a _ i ,",
+             r"E = m c ^ 2", r"\left( \begin{array} { c c } 1 & 0 \\ 0 & 1 \end{array} \right)", "a  b\n\n c",
+             "x_{12345} + 1000000", r"\alpha\beta <EOS>", "\u00e9\u03b1 \u4e2d"]
+    cases = [{"text": t, "ids": ref.encode(t), "decoded": ref.decode(ref.encode(t))} for t in texts]
+    with open(os.path.join(GOLD, "tokenizer_cases.json"), "w") as f:
+        json.dump({"vocab_size": ref.vocab_size, "special_tokens": ref.special_tokens, "cases": cases,
+                   "process_output": [[c["text"], ref_utils.process_output(c["text"])] for c in cases]}, f, indent=1,
+                  ensure_ascii=True)
+    print("[golden] tokenizer_cases.json", len(cases), "cases")
+
+
+CAPS = {"tokenizer": cap_tokenizer, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
         "window": cap_window, "sampling": cap_sampling}
 
 if __name__ == "__main__":

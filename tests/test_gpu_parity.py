@@ -375,3 +375,30 @@ def test_world1_rccl_allgather_smoke():
         assert torch.equal(got, want)
     finally:
         dist.destroy_process_group()
+
+
+def test_wrapper_end_to_end(tmp_path):
+    """N3: TeXOCRWrapper(config)(PIL image) -> (tokens, LaTeX string): tokenizer file, checkpoint file in the
+    reference's save_checkpoint layout (utils.py:52-61) with a shorter positional table (ocr_model.py:84-88)."""
+    import os
+    from PIL import Image
+    from texocr_amd.config import reference_config
+    from texocr_amd.wrapper import TeXOCRWrapper
+    cfg = reference_config(max_length=256)
+    d = Dims.from_config({**cfg, "max_length": 96})
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(d, 3).items()}
+    ckpt = tmp_path / "checkpoint_e1.pth"
+    torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "epoch": 1}, ckpt)
+    cfg["tokenizer_path"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_clean_1k.txt")
+    cfg["model_path"] = str(ckpt)
+    w = TeXOCRWrapper(cfg)
+    assert w.model.decoder.max_len == 96                      # taken from the checkpoint's positional table
+    img = Image.new("RGB", (200, 40), (255, 255, 255))
+    for x in range(20, 180, 7):
+        img.putpixel((x, 20), (0, 0, 0))
+    toks, text = w(img, max_len=20, decode="greedy")
+    assert len(toks) == 19 and isinstance(text, str)
+    toks2, text2 = w(img, max_len=20, decode="greedy")
+    assert toks2 == toks and text2 == text
+    toks3, _ = w(img, max_len=20, temp=0.3, seed=5)           # the reference's default decode: sampling
+    assert len(toks3) == 19

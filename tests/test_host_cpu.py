@@ -118,3 +118,38 @@ def test_sharded_generate_gloo_world2(total):
         exp_rows = np.concatenate([np.full((shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0], 2), r)
                                    for r in range(world)])
         assert np.array_equal(rows, exp_rows)
+
+
+def test_tokenizer_matches_reference_vectors():
+    """N4: vocabulary file format + byte-level BPE encode/decode against vectors produced by the reference's
+    RegExTokenizer on its own tokenizer_clean_1k.txt (data file copied under tests/golden/)."""
+    import json
+    from texocr_amd.tokenizer import RegExTokenizer, process_output
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = json.load(open(os.path.join(root, "tokenizer_cases.json")))
+    tk = RegExTokenizer()
+    tk.load(os.path.join(root, "tokenizer_clean_1k.txt"))
+    assert tk.vocab_size == g["vocab_size"] == 1000
+    assert tk.special_tokens == {"<PAD>": 999, "<BOS>": 998, "<EOS>": 997} == g["special_tokens"]
+    assert len(tk.bp_merges) == 741                       # 256 bytes + 741 merges + 3 specials (SURVEY section 2)
+    for c in g["cases"]:
+        assert tk.encode(c["text"]) == c["ids"], c["text"]
+        assert tk.decode(c["ids"]) == c["decoded"]
+    for text, want in g["process_output"]:
+        assert process_output(text) == want
+    # the survey's known answer
+    assert tk.encode(r"\int _ { 0 } ^ { 1 } x ^ 2 d x") == [615, 257, 258, 381, 261, 266, 258, 259, 261, 334, 266, 260, 264, 334]
+    assert process_output(r"\int _ { 0 } ^ { 1 } x ^ 2 d x") == r"\int_{0}^{1}x^2dx"
+    with pytest.raises(ValueError):
+        tk.decode([5000])
+
+
+def test_wrapper_preprocess():
+    from PIL import Image
+    from texocr_amd.wrapper import preprocess_image
+    img = Image.new("RGB", (50, 20), (255, 255, 255))
+    img.putpixel((3, 4), (0, 0, 0))
+    x = preprocess_image(img)
+    assert x.shape == (1, 32, 64) and x.dtype == torch.float32
+    # white -> 1 - (0.2989 + 0.587 + 0.114) = 1e-4 (torchvision's luma weights), black -> 1, padding = 0
+    assert float(x[0, 4, 3]) > 0.99 and float(x.sum()) < 1.2 and float(x[0, 25, 55]) == 0.0
