@@ -3,6 +3,7 @@
 #include "../../include/texocr.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -496,10 +497,19 @@ struct Engine : EngineBase {
         for (int l = 0; l < cfg.enc_layers; ++l) {
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
             else launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
-            launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
-                               EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N});
-            hipLaunchKernelGGL((enc_attn_kernel<T>), dim3((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads), dim3(256), 0,
-                               s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N, cfg.enc_heads);
+            const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);
+            if constexpr (sizeof(T) == 4) {
+                launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
+                                   EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N});
+                hipLaunchKernelGGL((enc_attn_kernel<T>), agrid, dim3(256), 0, s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N,
+                                   cfg.enc_heads);
+            } else {                                              // perf mode: bf16 q/k/v, bf16 MFMA attention
+                bf16* qb = reinterpret_cast<bf16*>(eqkv);
+                launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
+                                   EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N});
+                hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N,
+                                   cfg.enc_heads);
+            }
             launch_gemm_big<T>(s, LoadPlain<T>{eao, Ie}, enc_attn[l].wo, M, 2 * D, Ie,
                                EpiGluRes{ey, ex, enc_attn[l].bo, D});
             launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
@@ -586,20 +596,26 @@ struct Engine : EngineBase {
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
         constexpr int WBS = sizeof(T) == 2 ? 3 : 1;        // self: q,k,v weight rows requested together (bf16) or one by one
+        // profiling: hipExtLaunchKernelGGL binds the start/stop events to the dispatch itself (the kernel's own begin /
+        // end timestamps, what rocprofv3 reports), not to marker commands around it
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (prof && o.cross) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+        const bool timed = prof && o.cross;
+        if (timed) { e0 = pool.next(); e1 = pool.next(); }
         const bool narrow = (D & 255) != 0;
-#define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
-        do {                                                                                                  \
-            if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, true>), grid, blk, 0, s, a);  \
-            else hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, false>), grid, blk, 0, s, a);        \
+#define TXO_DA1(MODE, APRO, NLV, WBV, NARROW)                                                                         \
+        do {                                                                                                          \
+            if (timed) hipExtLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, NARROW>), grid, blk, 0, s, e0, e1, 0, a); \
+            else hipLaunchKernelGGL((dec_attn_kernel<T, MODE, APRO, NLV, WBV, NARROW>), grid, blk, 0, s, a);           \
         } while (0)
+#define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
+        do { if (narrow) TXO_DA1(MODE, APRO, NLV, WBV, true); else TXO_DA1(MODE, APRO, NLV, WBV, false); } while (0)
         if (o.cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
         else if (o.apro == APRO_NONE) TXO_DA(ATT_SELF, APRO_NONE, NLS, 1);
         else if (o.apro == APRO_EMBED) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
         else TXO_DA(ATT_SELF, APRO_LN2, NLS, WBS);
 #undef TXO_DA
-        if (prof && o.cross) { (void)hipEventRecord(e1, s); ev_cross.push_back({e0, e1}); }
+#undef TXO_DA1
+        if (timed) ev_cross.push_back({e0, e1});
     }
 
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
