@@ -281,6 +281,21 @@ def test_full_size_batch_independence_and_determinism():
     t3 = m.generate(img[perm].contiguous(), 256)
     assert torch.equal(t3, t1[perm])
     assert int(t1.min()) >= 0 and int(t1.max()) < d.vocab
+    # opt-in execution modes must give the same tokens: hipGraph replay of the step, two concurrent lanes, fused self QKV
+    import os
+    for env in ({"TXO_GRAPH": "1"}, {"TXO_GRAPH": "1", "TXO_LANES": "2"}, {"TXO_LANES": "4"}):
+        os.environ.update(env)
+        try:
+            assert torch.equal(m.generate(img, 256), t1), env
+        finally:
+            for k in env:
+                os.environ.pop(k)
+    # bucketed variable-width input (BASELINE config 5's input shape): per-image rows equal the fixed-width result
+    from texocr_amd.dist import generate_bucketed
+    mixed = [img[0], img[1, :, :, :448].contiguous(), img[2], img[3, :, :, :448].contiguous()]
+    rows = generate_bucketed(lambda b: m.generate(b, 32), mixed, max_batch=64)
+    assert torch.equal(torch.stack([rows[0], rows[2]]), m.generate(img[[0, 2]].contiguous(), 32))
+    assert rows[1].shape == (32,) and torch.equal(rows[1], m.generate(mixed[1][None].contiguous(), 32)[0])
 
 
 # ------------------------------------------------------------------------------------------------

@@ -153,3 +153,20 @@ def test_wrapper_preprocess():
     assert x.shape == (1, 32, 64) and x.dtype == torch.float32
     # white -> 1 - (0.2989 + 0.587 + 0.114) = 1e-4 (torchvision's luma weights), black -> 1, padding = 0
     assert float(x[0, 4, 3]) > 0.99 and float(x.sum()) < 1.2 and float(x[0, 25, 55]) == 0.0
+
+
+def test_generate_bucketed_groups_by_exact_size():
+    from texocr_amd.dist import generate_bucketed
+    g = torch.Generator().manual_seed(1)
+    sizes = [(16, 32), (16, 64), (16, 32), (32, 32), (16, 64), (16, 32), (16, 32)]
+    imgs = [torch.rand((1, h, w), generator=g) for h, w in sizes]
+    calls = []
+
+    def fn(batch):
+        calls.append(tuple(batch.shape))
+        return (batch.reshape(batch.shape[0], -1).sum(1, keepdim=True) * 100).long().expand(-1, 3)
+
+    out = generate_bucketed(fn, imgs, max_batch=3)
+    assert sorted(calls) == sorted([(3, 1, 16, 32), (1, 1, 16, 32), (2, 1, 16, 64), (1, 1, 32, 32)])
+    for im, o in zip(imgs, out):
+        assert int(o[0]) == int(im.sum() * 100) and o.shape == (3,)

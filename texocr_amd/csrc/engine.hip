@@ -63,16 +63,6 @@ struct EngineBase {
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
 };
 
-static std::vector<std::string> stack_kinds(bool dec, int layers) {
-    std::vector<std::string> k;
-    for (int l = 0; l < layers; ++l) {
-        k.push_back("self");
-        if (dec) k.push_back("cross");
-        k.push_back("mlp");
-    }
-    return k;
-}
-
 // rows [2X][K] -> groups of 32 rows: 16 "value" rows (g*16..) followed by their 16 "gate" rows (X + g*16..)
 static std::vector<float> interleave16(const std::vector<float>& w, int X, int K) {
     std::vector<float> o((size_t)2 * X * K);

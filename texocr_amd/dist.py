@@ -87,3 +87,23 @@ def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor]
         raise ValueError("generate_local must decode exactly max_len steps (eos break disabled)")
     full = all_gather_rows(toks, counts, group)
     return full[:, :global_eos_steps(full, eos, bos)]
+
+
+def generate_bucketed(generate_fn: Callable[[torch.Tensor], torch.Tensor], images, max_batch: int = 64):
+    """Variable-size inputs: group images of identical (H, W) into batches, exactly like the reference's
+    BucketBatchSampler (data_wrangling/dataset.py:281-326 buckets by exact (w, h), :306-310), run each bucket through
+    ``generate_fn(batch) -> (b, n) tokens`` and return the per-image token rows in the original order.
+    Each bucket keeps the reference's GLOBAL eos break among its own rows, as a reference batch would."""
+    buckets = {}
+    for i, im in enumerate(images):
+        if im.ndim != 3:
+            raise ValueError("each image must be (C, H, W)")
+        buckets.setdefault((int(im.shape[1]), int(im.shape[2])), []).append(i)
+    out = [None] * len(images)
+    for _, idx in sorted(buckets.items()):
+        for lo in range(0, len(idx), max_batch):
+            part = idx[lo: lo + max_batch]
+            toks = generate_fn(torch.stack([images[i] for i in part]).contiguous())
+            for j, i in enumerate(part):
+                out[i] = toks[j]
+    return out
