@@ -155,12 +155,19 @@ def main():
                     traffic = pm["traffic_bytes"]
             except Exception:
                 pass
+            # encoder (patch-embed + ViT stack) FLOPs per image, SURVEY 8d: 2(N-1)C*256*D + Le*(N(10DI + 6DF) + 4N^2 I)
+            D_, I_, F_, Le = dims.embed_dim, dims.enc_inner, dims.enc_ffn, dims.enc_layers
+            enc_flop = a.batch * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
+            mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3          # dense TFLOP/s, MI355X_MICROARCH.md
+            enc_tf = enc_flop / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                                   "traffic": traffic, "algorithmic_bytes_per_launch": algo,
                                   "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
-                                  "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1)}
+                                  "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1),
+                                  "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                                                   "frac": round(enc_tf / mfma_peak, 4)}}
         if not a.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(dims, sd_np, a)
         print(json.dumps(result), flush=True)

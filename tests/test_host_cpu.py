@@ -91,6 +91,9 @@ def _worker(rank, world, port, total, q):
         out = sharded_generate(_fake_generate, imgs, 10, eos=5, bos=12)
         lo, hi = shard_bounds(total, rank, world)
         out2 = sharded_generate(_fake_generate, imgs[lo:hi], 10, eos=5, bos=12, images_are_local=True, global_batch=total)
+        tk, lg = sharded_generate(lambda x, n: (_fake_generate(x, n), _fake_generate(x, n)[..., None].float() * torch.ones(3)),
+                                  imgs, 10, eos=5, bos=12, gather_logits=True)
+        assert torch.equal(tk, out) and lg.shape == (out.shape[0], out.shape[1], 3) and torch.equal(lg[..., 0].long(), out)
         rows = all_gather_rows(torch.full((hi - lo, 2), rank), [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]
                                                                for r in range(world)])
         q.put((rank, out.numpy(), out2.numpy(), rows.numpy()))

@@ -59,17 +59,22 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch
 
 def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images: torch.Tensor, max_len: int,
                      eos: Optional[int], bos: Optional[int] = None, group=None,
-                     images_are_local: bool = False, global_batch: Optional[int] = None) -> torch.Tensor:
+                     images_are_local: bool = False, global_batch: Optional[int] = None, gather_logits: bool = False):
     """Data-parallel generate.
 
     generate_local(img_shard, max_len) -> (b_local, max_len) int64 tokens decoded WITHOUT the eos break
     (e.g. ``lambda x, n: model._engine.generate(x, n, eos=None)``).
     `images` is either the global batch (every rank holds it; the rank's shard is sliced out) or, with
     images_are_local=True, already this rank's shard (then `global_batch` gives the total row count).
-    Returns the GLOBAL (B, n_steps) token tensor on every rank."""
+    Returns the GLOBAL (B, n_steps) token tensor on every rank.  With gather_logits=True, generate_local returns
+    (tokens, logits (b_local, max_len, V)) and the per-step logits are all-gathered as well (one more collective,
+    B/G * T * V * 4 bytes per rank -- 65 MB at 64 x 256 x 1000), returning (tokens, logits)."""
+    def unpack(r):
+        return r if gather_logits else (r, None)
     if not dist.is_initialized():
-        toks = generate_local(images, max_len)
-        return toks[:, :global_eos_steps(toks, eos, bos)]
+        toks, lg = unpack(generate_local(images, max_len))
+        n = global_eos_steps(toks, eos, bos)
+        return (toks[:, :n], lg[:, :n]) if gather_logits else toks[:, :n]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if images_are_local:
         total = global_batch if global_batch is not None else images.shape[0] * world
@@ -81,12 +86,16 @@ def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor]
     counts = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
     if local.shape[0] != counts[rank]:
         raise ValueError(f"rank {rank} holds {local.shape[0]} images, expected {counts[rank]}")
-    toks = generate_local(local, max_len) if local.shape[0] else torch.empty((0, max_len), dtype=torch.int64,
-                                                                              device=images.device)
+    if not local.shape[0]:
+        raise ValueError("every rank needs at least one image")
+    toks, lg = unpack(generate_local(local, max_len))
     if toks.shape[1] != max_len:
         raise ValueError("generate_local must decode exactly max_len steps (eos break disabled)")
     full = all_gather_rows(toks, counts, group)
-    return full[:, :global_eos_steps(full, eos, bos)]
+    n = global_eos_steps(full, eos, bos)
+    if gather_logits:
+        return full[:, :n], all_gather_rows(lg, counts, group)[:, :n]
+    return full[:, :n]
 
 
 def generate_bucketed(generate_fn: Callable[[torch.Tensor], torch.Tensor], images, max_batch: int = 64):
