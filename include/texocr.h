@@ -98,6 +98,16 @@ int txo_generate_from_enc(txo_engine* e, const float* enc_dev, int32_t B, int32_
                           int32_t eos, int64_t* tokens_out_dev, int32_t* n_steps_out, float* logits_out_dev,
                           void* stream);
 
+/* Beam search over txo_generate's loop -- a BUILD EXTENSION: the reference has no beam search (BASELINE config 5 asks for
+ * k = 5), so parity is anchored only at beams = 1 (== greedy).  Score = sum of log_softmax(logits) of the chosen tokens
+ * (not length-normalised); a beam that has emitted eos is finished and continues with eos at no cost; the loop stops when
+ * every beam of every image is finished.  Needs cfg.max_batch >= B * beams, beams <= 8.  tokens_out [B, max_len] receives
+ * the best beam per image; scores_out [B, beams] (may be NULL) the final scores, best first; all_tokens_out
+ * [B * beams, max_len] (may be NULL) every beam. */
+int txo_generate_beam(txo_engine* e, const float* img_dev, int32_t B, int32_t C, int32_t H, int32_t W, int32_t beams,
+                      int32_t max_len, int32_t eos, int64_t* tokens_out_dev, float* scores_out_dev,
+                      int64_t* all_tokens_out_dev, int32_t* n_steps_out, void* stream);
+
 /* Token selection for the following decode steps / generate calls.  mode 0 (default): greedy argmax.  mode 1:
  * the reference's sampler (decoder.py:104-108 + utils.topk, utils.py:85-91): keep the `topk` largest logits
  * (the reference uses int((1 - 0.9) * vocab) = 99 for vocab 1000), softmax(logits / temp), one multinomial draw,

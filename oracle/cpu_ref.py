@@ -344,3 +344,41 @@ def teacher_forced_logits_cached(sd: SD, enc: torch.Tensor, tokens: torch.Tensor
 def sample_probs(logits: torch.Tensor, temp: float) -> torch.Tensor:
     """The reference's sampling distribution for one step (decoder.py:104-107)."""
     return F.softmax(topk_filter(logits) / temp, dim=-1)
+
+
+# --------------------------------------------------------------------------------------
+# beam search -- NOT in the reference (SURVEY D3): parity is unpinned except k = 1 == greedy.
+# Definition used by the build: length-unnormalised sum of log_softmax(logits); k beams per image, only beam 0 live at
+# step 0; a beam that has emitted eos is finished and continues with eos at no cost; candidates are ranked by score with
+# ties broken by the lower flat index (beam * V + token); stop when every beam of every image is finished.
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def beam_search_cached(sd: SD, enc: torch.Tensor, bos: int, eos: Optional[int], max_len: int, k: int):
+    """Returns (tokens (B, k, n), scores (B, k)) sorted by score, best first."""
+    B = enc.shape[0]
+    V = sd["decoder.net.to_logits.weight"].shape[0]
+    dec = CachedDecoder(sd, enc.repeat_interleave(k, dim=0))
+    tok = torch.full((B * k,), bos, dtype=torch.long)
+    score = torch.full((B, k), -float("inf"))
+    score[:, 0] = 0.0
+    fin = torch.zeros((B, k), dtype=torch.bool)
+    hist = torch.zeros((B, k, 0), dtype=torch.long)
+    for _ in range(max_len):
+        logp = F.log_softmax(dec.step(tok), dim=-1).view(B, k, V)
+        if eos is not None:
+            frozen = torch.full_like(logp, -float("inf"))
+            frozen[..., eos] = 0.0
+            logp = torch.where(fin[..., None], frozen, logp)
+        cand = (score[..., None] + logp).view(B, k * V)
+        # top-k with lowest-flat-index tie break: stable sort on (-value, index)
+        order = torch.sort(cand, dim=1, descending=True, stable=True).indices[:, :k]
+        score = torch.gather(cand, 1, order)
+        parent, token = order // V, order % V
+        hist = torch.cat([torch.gather(hist, 1, parent[..., None].expand(-1, -1, hist.shape[2])), token[..., None]], dim=2)
+        fin = torch.gather(fin, 1, parent) | ((token == eos) if eos is not None else torch.zeros_like(fin))
+        rows = (torch.arange(B)[:, None] * k + parent).reshape(-1)
+        dec.self_kv = {s_: (kk[rows], vv[rows]) for s_, (kk, vv) in dec.self_kv.items()}
+        tok = token.reshape(-1)
+        if eos is not None and bool(fin.all()):
+            break
+    return hist, score

@@ -417,3 +417,32 @@ def test_wrapper_end_to_end(tmp_path):
     assert toks2 == toks and text2 == text
     toks3, _ = w(img, max_len=20, temp=0.3, seed=5)           # the reference's default decode: sampling
     assert len(toks3) == 19
+
+
+def test_beam_search_extension():
+    """BASELINE config 5 asks for beam search; the reference has none, so parity is anchored at
+    beams=1 == greedy, plus agreement with the oracle's independent CPU restatement of the same definition."""
+    cpu_ref = _oracle()
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=0, max_batch=12)
+    img = torch.from_numpy(synth.synth_images(3, 3, 64, 96, seed=41))
+    m.eos_token = None
+    greedy = m.generate(img.cuda(), 24)
+    assert torch.equal(m.generate(img.cuda(), 24, beam=1), greedy)
+    sdt = cpu_ref.to_torch_sd(sd)
+    enc = cpu_ref.encode(sdt, img)
+    for k, eos in ((4, None), (3, int(greedy[0, 5]))):
+        m.eos_token = eos
+        toks, scores = m.generate(img.cuda(), 24, beam=k, return_beams=True)
+        ref_t, ref_s = cpu_ref.beam_search_cached(sdt, enc, d.bos, eos, 24, k)
+        assert toks.shape[:2] == (3, k) and toks.shape[2] == ref_t.shape[2]
+        np.testing.assert_allclose(scores.cpu().numpy(), ref_s.numpy(), atol=2e-3)
+        assert bool((scores[:, :-1] >= scores[:, 1:]).all())                  # best first
+        assert torch.equal(toks.cpu(), ref_t), (k, eos)
+        best = m.generate(img.cuda(), 24, beam=k)
+        assert torch.equal(best, toks[:, 0])
+        assert torch.equal(m.generate(img.cuda(), 24, beam=k), best)          # deterministic
+    with pytest.raises(ValueError):
+        m.generate(img.cuda(), 24, beam=9)
+    with pytest.raises(ValueError):
+        m.generate(torch.rand(5, 3, 64, 96, device="cuda"), 24, beam=3)       # 15 rows > max_batch 12

@@ -46,6 +46,10 @@ template <typename T> struct DecAttnArgs {
     int heads, lmax;
     int len;                        // cross: number of keys
     const int* t_ptr;               // decode position (device)
+    // beam search: rows are (image, beam) slots.  Cross K/V are shared by the kv_div beams of an image; a beam's
+    // self-attention history is scattered over slots: position p of row r lives in slot path[r*path_stride + p].
+    int kv_div;                     // cross: K/V image = row / kv_div (1 without beams)
+    const short* path; int path_stride;   // self (APRO_NONE): null without beams
 };
 
 template <typename T, int PER16>
@@ -88,7 +92,7 @@ __device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX]
 // The hot loops are written WITHOUT data-dependent branches (clamped unconditional loads, masked scores of
 // -3e38 whose exp is exactly 0, selects): a guarded load becomes its own basic block and hipcc's waitcnt
 // insertion then falls back to vmcnt(0) per iteration, which serialises the whole K/V stream.
-template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW>
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false>
 __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int LPR = DH / PER16;          // lanes per 64-element row: 16 (f32) / 8 (bf16)
@@ -103,10 +107,12 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane % LPR, kq = lane / LPR;
     const int D = a.D, inner = a.heads * DH;
-    T* Kb = a.K + (size_t)bh * a.lmax * DH;
-    T* Vb = a.V + (size_t)bh * a.lmax * DH;
+    const int kvimg = MODE == ATT_CROSS ? img / a.kv_div : img;
+    T* Kb = a.K + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
+    T* Vb = a.V + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
 
     __shared__ __attribute__((aligned(16))) float zs[768];   // normalised row
+    __shared__ short pth[BEAM ? 1024 : 1];                   // beam: slot of every history position of this row
     __shared__ __attribute__((aligned(16))) float qkv[3][DH];
     __shared__ float part[4][DH];
     __shared__ float stat[12];
@@ -135,16 +141,26 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     const int L = MODE == ATT_CROSS ? a.len : (FUSED ? t : t + 1);
     const int Lm1 = max(L - 1, 0);
     const int key0 = wave * KPI + kq;
+    // byte-row address of key `key` in the K (or V) panel: own slot, or (beam) the slot recorded for that position
+    const size_t slot_stride = (size_t)a.heads * a.lmax * DH;
+    auto row_off = [&](int key) -> long long {
+        if constexpr (BEAM) return (long long)((int)pth[key] - img) * (long long)slot_stride + (long long)key * DH;   // relative to the own slot
+        else return (long long)key * DH;
+    };
+    if constexpr (BEAM) {
+        for (int p = tid; p < L; p += 256) pth[p] = p == L - 1 ? (short)img : a.path[(size_t)img * a.path_stride + p];
+        __syncthreads();
+    }
     u32x4 rk[NL], rv[NL];
     // small panels (self attention) request V together with K; long ones (cross) request each V row as its K
     // registers are consumed, which halves the live panel (K and V of NL = 20 would not fit 256 VGPRs)
     constexpr bool V_EARLY = MODE == ATT_SELF;
     auto issue_k = [&](int base) {
 #pragma unroll
-        for (int u = 0; u < NL; ++u) rk[u] = ld16(Kb + (size_t)min(base + u * KPB + key0, Lm1) * DH + sub * PER16);
+        for (int u = 0; u < NL; ++u) rk[u] = ld16(Kb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
         if constexpr (V_EARLY) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u) rv[u] = ld16(Vb + (size_t)min(base + u * KPB + key0, Lm1) * DH + sub * PER16);
+            for (int u = 0; u < NL; ++u) rv[u] = ld16(Vb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
         }
     };
     issue_k(0);
@@ -287,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
 #pragma unroll
             for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
             // the K registers of this slot are dead now: request the matching V rows into their place
-            if constexpr (!V_EARLY) rv[u] = ld16(Vb + (size_t)min(key, Lm1) * DH + sub * PER16);
+            if constexpr (!V_EARLY) rv[u] = ld16(Vb + row_off(min(key, Lm1)) + sub * PER16);
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // butterfly: all LPR lanes get the dot
             d = key < L ? d : -3.0e38f;

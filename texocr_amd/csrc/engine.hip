@@ -58,6 +58,9 @@ struct EngineBase {
     virtual int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) = 0;
     virtual int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                          int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) = 0;
+    virtual int generate_beam(const float* img, const float* enc, int B, int C, int H, int W, int N, int beams, int max_len,
+                              int eos, int64_t* tokens_out, float* scores_out, int64_t* all_tokens_out, int* n_steps,
+                              hipStream_t s) = 0;
     int sample_mode = 0, sample_topk = 0; float sample_temp = 1.f; unsigned long long sample_seed = 0;
     virtual int profile_enable(int on) = 0;
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
@@ -125,7 +128,10 @@ struct Engine : EngineBase {
     hipStream_t cap_stream = nullptr;      // graphs are captured here, never on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
     int64_t* tok_buf = nullptr;            // [Bmax][Tmax] generated ids (engine-owned so graphs do not bake user pointers)
-    int sB = 0, sN = 0; bool session = false;
+    int sB = 0, sN = 0, sImg = 0; bool session = false;   // decode rows, encoder tokens, images behind the cross K/V cache
+    // beam search state (rows = images * beams)
+    float* bscore = nullptr; int* bfin = nullptr; short* bpath[2] = {nullptr, nullptr}; short* bparent = nullptr; int* btok = nullptr;
+    struct BeamCtx { int k; const short* path_cur; short* path_nxt; };
     // ----- profiling -----
     bool prof = false; EventPool pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_cross, ev_enc, ev_step;
@@ -384,6 +390,12 @@ struct Engine : EngineBase {
         if (int r = dalloc(&done_flag, (size_t)Tmax * MAXL)) return r;
         if (int r = dalloc(&st, MAXL)) return r;
         if (int r = dalloc(&tok_buf, (size_t)Bmax * Tmax)) return r;
+        if (int r = dalloc(&bscore, (size_t)Bmax)) return r;
+        if (int r = dalloc(&bfin, (size_t)Bmax)) return r;
+        if (int r = dalloc(&bpath[0], (size_t)Bmax * Tmax)) return r;
+        if (int r = dalloc(&bpath[1], (size_t)Bmax * Tmax)) return r;
+        if (int r = dalloc(&bparent, (size_t)Bmax * Tmax)) return r;
+        if (int r = dalloc(&btok, (size_t)Bmax * Tmax)) return r;
         HIP_TRY(hipMemset(st, 0, sizeof(StepState) * MAXL));
         max_lanes = MAXL;
         if (max_lanes < 1) max_lanes = 1;
@@ -527,7 +539,7 @@ struct Engine : EngineBase {
         // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D]
         launch_gemm_big<T>(s, LoadPlain<T>{a_enc, D}, wckv, M, cfg.dec_layers * 2 * Id, D,
                            EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, N});
-        sB = B; sN = N; session = true;
+        sB = B; sN = N; sImg = B; session = true;
         set_lanes(1, s);
         reset_lanes(s, eos);
         HIP_TRY(hipGetLastError());
@@ -573,6 +585,7 @@ struct Engine : EngineBase {
         bool cross = false; int apro = APRO_LN2;
         const T* W = nullptr; T* K = nullptr; T* V = nullptr; int lmax = 0, len = 0;
         float* x_out = nullptr;
+        int kv_div = 1; const short* path = nullptr;      // beam search: shared cross K/V, scattered self history
     };
     void launch_dec_attn(hipStream_t s, int li, const AttnOpt& o) {
         const Lane& ln = lanes[li];
@@ -582,7 +595,7 @@ struct Engine : EngineBase {
         a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = o.W;
         a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
         a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t;
-        a.qin = dq + r0 * Id;
+        a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path; a.path_stride = Tmax;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
         constexpr int WBS = sizeof(T) == 2 ? 3 : 1;        // self: q,k,v weight rows requested together (bf16) or one by one
@@ -600,6 +613,10 @@ struct Engine : EngineBase {
 #define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
         do { if (narrow) TXO_DA1(MODE, APRO, NLV, WBV, true); else TXO_DA1(MODE, APRO, NLV, WBV, false); } while (0)
         if (o.cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
+        else if (o.apro == APRO_NONE && o.path) {
+            if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, true, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, false, true>), grid, blk, 0, s, a);
+        }
         else if (o.apro == APRO_NONE) TXO_DA(ATT_SELF, APRO_NONE, NLS, 1);
         else if (o.apro == APRO_EMBED) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
         else TXO_DA(ATT_SELF, APRO_LN2, NLS, WBS);
@@ -609,7 +626,8 @@ struct Engine : EngineBase {
     }
 
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
-    int enqueue_step(hipStream_t s, int li, int64_t* tokens_out, int out_stride, float* logits_out, int eos) {
+    int enqueue_step(hipStream_t s, int li, int64_t* tokens_out, int out_stride, float* logits_out, int eos,
+                     const BeamCtx* bm = nullptr) {
         const Lane& ln = lanes[li];
         const int B = sB, N = sN, nb = ln.nb;
         const size_t r0 = ln.b0;
@@ -620,12 +638,13 @@ struct Engine : EngineBase {
         base.inner = Id; base.heads = cfg.dec_heads; base.tmax = Tmax;
         float* lx = dx + r0 * D; float* ly = dy + r0 * D; T* lao = dao + r0 * Id; T* lhid = dhid + r0 * Fd;
         float* llog = dlogits + r0 * V;
-        const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)B * N * Id;
+        const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)sImg * N * Id;
         for (int l = 0; l < cfg.dec_layers; ++l) {
             T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
             {   // causal self attention
                 AttnOpt o; o.W = dec_self[l].wqkv; o.K = kc; o.V = vc; o.lmax = Tmax; o.x_out = lx;
-                if (self_plain) {
+                if (bm) o.path = bm->path_cur;
+                if (self_plain || bm) {
                     // default: LN sandwich + QKV GEMM (weights read once per 16 rows; k/v appended to the cache by
                     // its epilogue), then the plain cached attention.  TXO_SELF_FUSED=1 folds the projection into
                     // the attention launch instead (same wall time at B=64; re-reads 96 KB of weights per image).
@@ -648,6 +667,7 @@ struct Engine : EngineBase {
             {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
                 AttnOpt o; o.cross = true; o.W = dec_cross[l].wq; o.K = ckv + (size_t)(2 * l) * cross_stride;
                 o.V = ckv + (size_t)(2 * l + 1) * cross_stride; o.lmax = N; o.len = N; o.x_out = lx;
+                if (bm) o.kv_div = bm->k;
                 launch_dec_attn(s, li, o);
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
@@ -673,7 +693,11 @@ struct Engine : EngineBase {
                     logits_out ? logits_out + r0 * (size_t)out_stride * V : nullptr, st + li, eos_seen + r0,
                     done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp,
                     sample_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)r0};
-        if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(nb), dim3(64), (size_t)V * sizeof(float), s, sa);
+        if (bm) {
+            BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok, bscore, bfin, bm->path_cur, bm->path_nxt, Tmax, bparent, btok, Bmax,
+                        st + li, done_flag + (size_t)li * Tmax, eos};
+            hipLaunchKernelGGL(beam_select_kernel, dim3(nb / bm->k), dim3(256), 0, s, ba);
+        } else if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(nb), dim3(64), (size_t)V * sizeof(float), s, sa);
         else hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
         dbg(s, "argmax");
         if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
@@ -776,6 +800,56 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
         set_lanes(1, s);
+        if (n_steps) *n_steps = steps;
+        return 0;
+    }
+
+    int generate_beam(const float* img, const float* enc, int B, int C, int H, int W, int N, int beams, int max_len, int eos,
+                      int64_t* tokens_out, float* scores_out, int64_t* all_tokens_out, int* n_steps, hipStream_t s) override {
+        if (beams < 1 || beams > 8) return fail(TXO_E_INVALID, "beams must be in [1, 8]");
+        if (max_len < 1 || max_len > Tmax)
+            return fail(TXO_E_INVALID, "max_len exceeds the decoder's max_length (a KV cache cannot slide the window)");
+        if (Tmax > 1024) return fail(TXO_E_INVALID, "beam search supports max_length <= 1024");
+        const int rows = B * beams;
+        if (B < 1 || rows > Bmax || rows > 32767) return fail(TXO_E_INVALID, "images * beams exceeds engine max_batch");
+        if (img) {
+            if (int r = encode(img, B, C, H, W, eenc, s)) return r;
+            enc = eenc; N = 1 + (H / 16) * (W / 16);
+        }
+        if (int r = decode_begin(enc, B, N, eos, s)) return r;       // cross K/V of the B images
+        sB = rows; sImg = B;                                          // decode rows are (image, beam) slots
+        set_lanes(1, s);
+        const int n = std::max(rows, Tmax);
+        hipLaunchKernelGGL(beam_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, cur_tok, bscore, bfin, done_flag, rows,
+                           beams, Tmax, cfg.bos);
+        std::vector<int> flags(max_len, 0);
+        int steps = max_len, cur = 0;
+        const int CHUNK = 32;
+        for (int t = 0; t < max_len; ++t) {
+            BeamCtx bm{beams, bpath[cur], bpath[cur ^ 1]};
+            if (int r2 = enqueue_step(s, 0, nullptr, 0, nullptr, eos, &bm)) return r2;
+            cur ^= 1;
+            if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
+                const int lo = (t / CHUNK) * CHUNK;
+                HIP_TRY(hipMemcpyAsync(flags.data() + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                bool stop = false;
+                for (int i = lo; i <= t && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
+                if (stop) break;
+            }
+        }
+        // backtrack every beam into tok_buf rows, then hand out the best beam (slot 0: selection order is by score)
+        hipLaunchKernelGGL(beam_backtrack_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, bparent, btok, Bmax, steps, rows,
+                           tok_buf, Tmax);
+        HIP_TRY(hipMemcpy2DAsync(tokens_out, sizeof(int64_t) * max_len, tok_buf, sizeof(int64_t) * Tmax * beams,
+                                 sizeof(int64_t) * steps, B, hipMemcpyDeviceToDevice, s));
+        if (all_tokens_out)
+            HIP_TRY(hipMemcpy2DAsync(all_tokens_out, sizeof(int64_t) * max_len, tok_buf, sizeof(int64_t) * Tmax,
+                                     sizeof(int64_t) * steps, rows, hipMemcpyDeviceToDevice, s));
+        if (scores_out) HIP_TRY(hipMemcpyAsync(scores_out, bscore, sizeof(float) * rows, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
+        sB = B;
         if (n_steps) *n_steps = steps;
         return 0;
     }
@@ -886,6 +960,13 @@ int txo_generate_from_enc(txo_engine* e, const float* enc, int32_t B, int32_t N,
                           int64_t* tokens_out, int32_t* n_steps, float* logits_out, void* stream) {
     if (!e || !enc || !tokens_out) return fail(TXO_E_INVALID, "null argument");
     return e->impl->generate(nullptr, enc, B, 0, 0, 0, N, max_len, eos, tokens_out, n_steps, logits_out, (hipStream_t)stream);
+}
+
+int txo_generate_beam(txo_engine* e, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t beams, int32_t max_len,
+                      int32_t eos, int64_t* tokens_out, float* scores_out, int64_t* all_tokens_out, int32_t* n_steps, void* stream) {
+    if (!e || !img || !tokens_out) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->generate_beam(img, nullptr, B, C, H, W, 0, beams, max_len, eos, tokens_out, scores_out, all_tokens_out, n_steps,
+                                  (hipStream_t)stream);
 }
 
 int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed) {

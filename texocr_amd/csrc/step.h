@@ -183,6 +183,120 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     if (lane == 0) commit_token(a, row, t, pick);
 }
 
+// ---- beam search (a build extension: the reference has no beam search) -----------------------------------
+// Length-unnormalised sum of log_softmax(logits); k beams per image, only beam 0 live at step 0; a beam that has
+// emitted eos is finished and continues with eos at no cost; candidates ranked by score, ties -> lower flat index
+// (beam * V + token); the loop stops when every beam of every image is finished.
+struct BeamArgs {
+    const float* logits; int V, k, images;
+    int64_t* cur_tok;                     // [images*k] token fed to the next step
+    float* score; int* fin;               // [images*k] running log-prob, finished flag (updated in place)
+    const short* path_cur; short* path_nxt; int path_stride;   // [rows][tmax] slot of every history position
+    short* parent_hist; int* tok_hist; int hist_stride;        // [tmax][rows] back-pointers for the final backtrack
+    StepState* st; int* done_flag; int eos;
+};
+
+__global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
+    constexpr int KMAX = 8;
+    __shared__ float red[8], s_lse[KMAX], s_score[KMAX], selv[KMAX];
+    __shared__ int redi[4], s_fin[KMAX], seli[KMAX];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.k, V = a.V, t = a.st->t;
+    const float* lg = a.logits + (size_t)img * k * V;
+    if (tid < k) { s_score[tid] = a.score[img * k + tid]; s_fin[tid] = a.fin[img * k + tid]; }
+    // log-sum-exp of every beam's row
+    for (int j = 0; j < k; ++j) {
+        float mx = -3.4e38f;
+        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, lg[(size_t)j * V + v]);
+        mx = wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float se = 0.f;
+        for (int v = tid; v < V; v += 256) se += expf(lg[(size_t)j * V + v] - mx);
+        se = wave_sum(se);
+        if (lane == 0) red[4 + wave] = se;
+        __syncthreads();
+        if (tid == 0) s_lse[j] = mx + logf((red[4] + red[5]) + (red[6] + red[7]));
+        __syncthreads();
+    }
+    // k rounds of block-wide arg max over the k*V candidates, excluding what was already taken
+    const int total = k * V;
+    for (int r = 0; r < k; ++r) {
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int f = tid; f < total; f += 256) {
+            bool taken = false;
+            for (int q = 0; q < r; ++q) taken |= seli[q] == f;
+            if (taken) continue;
+            const int j = f / V, v = f - j * V;
+            float c;
+            if (s_fin[j]) c = (v == a.eos) ? s_score[j] : -INFINITY;
+            else c = s_score[j] + (lg[f] - s_lse[j]);
+            if (c > best || (c == best && f < bi)) { best = c; bi = f; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float b = red[0]; int i = redi[0];
+            for (int w = 1; w < 4; ++w) if (red[w] > b || (red[w] == b && redi[w] < i)) { b = red[w]; i = redi[w]; }
+            selv[r] = b; seli[r] = i;
+        }
+        __syncthreads();
+    }
+    // new beams: slot r of this image continues beam seli[r] / V with token seli[r] % V
+    int allfin = 1;
+    for (int r = 0; r < k; ++r) {
+        const int j = seli[r] / V, v = seli[r] - j * V;
+        const int nf = s_fin[j] | ((a.eos >= 0 && v == a.eos) ? 1 : 0);
+        allfin &= nf;
+        if (tid == r) {
+            const int row = img * k + r;
+            a.score[row] = selv[r]; a.fin[row] = nf; a.cur_tok[row] = v;
+            a.tok_hist[(size_t)t * a.hist_stride + row] = v;
+            a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(img * k + j);
+        }
+        // history slots of the new beam: the parent's, plus the parent's own slot for position t
+        const short* src = a.path_cur + (size_t)(img * k + j) * a.path_stride;
+        short* dst = a.path_nxt + (size_t)(img * k + r) * a.path_stride;
+        for (int p = tid; p < t; p += 256) dst[p] = src[p];
+        if (tid == 0) dst[t] = (short)(img * k + j);
+    }
+    if (tid == 0) {
+        const unsigned add = 1u + ((a.eos >= 0 && allfin) ? (1u << 16) : 0u);
+        const unsigned old = atomicAdd(&a.st->arrive, add);
+        if ((old & 0xffffu) == (unsigned)(a.images - 1)) {
+            a.done_flag[t] = (int)((old + add) >> 16) >= a.images ? 1 : 0;
+            a.st->arrive = 0u;
+            a.st->t = t + 1;
+        }
+    }
+}
+
+__global__ void beam_reset_kernel(StepState* st, int64_t* cur_tok, float* score, int* fin, int* done_flag, int rows, int k,
+                                  int n_flags, int bos) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) { cur_tok[i] = bos; score[i] = (i % k == 0) ? 0.f : -INFINITY; fin[i] = 0; }
+    if (i < n_flags) done_flag[i] = 0;
+    if (i == 0) { st->t = 0; st->rows_with_eos = 0; st->arrive = 0u; st->pad = 0; }
+}
+
+// follow the back-pointers from the last step: tokens_all[row][0..n)
+__global__ void beam_backtrack_kernel(const short* parent_hist, const int* tok_hist, int hist_stride, int n, int rows,
+                                      int64_t* tokens_all, int out_stride) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    int cur = row;
+    for (int t = n - 1; t >= 0; --t) {
+        tokens_all[(size_t)row * out_stride + t] = tok_hist[(size_t)t * hist_stride + cur];
+        cur = parent_hist[(size_t)t * hist_stride + cur];
+    }
+}
+
 // (re)start a decode: position 0, BOS everywhere; a BOS that equals eos already satisfies the check
 __global__ void reset_state_kernel(StepState* st, int64_t* cur_tok, int* eos_seen, int* done_flag, int rows,
                                    int n_flags, int bos, int eos) {

@@ -165,6 +165,23 @@ class HipEngine:
         toks = toks[:, :n.value]
         return (toks, logits[:, :n.value]) if return_logits else toks
 
+    def generate_beam(self, img: torch.Tensor, beams: int, max_len: int, eos: Optional[int], return_beams: bool = False):
+        """Beam search (build extension; the reference has none).  Returns the best beam's tokens (B, n), or with
+        return_beams=True (tokens (B, beams, n), scores (B, beams)) sorted best first."""
+        src = _dev_f32(img, "src")
+        B, Cc, H, W = src.shape
+        self.dims.check_image(Cc, H, W)
+        toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
+        scores = torch.empty((B, beams), device=src.device, dtype=torch.float32)
+        allt = torch.empty((B * beams, max_len), device=src.device, dtype=torch.int64) if return_beams else None
+        n = C.c_int32(0)
+        _lib.check(self.lib.txo_generate_beam(self.handle, src.data_ptr(), B, Cc, H, W, int(beams), int(max_len),
+                                              -1 if eos is None else int(eos), toks.data_ptr(), scores.data_ptr(),
+                                              allt.data_ptr() if return_beams else None, C.byref(n), _stream()))
+        if return_beams:
+            return allt[:, :n.value].reshape(B, beams, n.value), scores
+        return toks[:, :n.value]
+
     def set_sampling(self, on: bool, temp: float = 1.0, seed: int = 0, threshold: float = 0.9) -> None:
         """on=True: the reference sampler (top-k with k = int((1 - threshold) * vocab), utils.py:85-91 -- 99 for
         vocab 1000 because of float rounding -- then softmax(/temp) and one multinomial draw, decoder.py:104-108)."""
@@ -316,7 +333,10 @@ class OCRModel:
 
     @torch.no_grad()
     def generate(self, src: torch.Tensor, max_len: int, temp: float = 0.3, *, decode: str = "greedy",
-                 generator: Optional[torch.Generator] = None, seed: Optional[int] = None, return_logits: bool = False):
+                 generator: Optional[torch.Generator] = None, seed: Optional[int] = None, return_logits: bool = False,
+                 beam: int = 0, return_beams: bool = False):
+        if beam:                                           # build extension (BASELINE config 5); engine max_batch >= B * beam
+            return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
         if decode == "greedy" and self.bos_token == self._engine.dims.bos:
             if max_len > self.decoder.max_len:
                 raise ValueError(f"max_len {max_len} exceeds decoder.max_len {self.decoder.max_len}: the reference "
