@@ -50,6 +50,7 @@ template <typename T> struct DecAttnArgs {
     // self-attention history is scattered over slots: position p of row r lives in slot path[r*path_stride + p].
     int kv_div;                     // cross: K/V image = row / kv_div (1 without beams)
     const short* path; int path_stride;   // self (APRO_NONE): null without beams
+    unsigned long long* stamps;     // diagnostic (TXO_STAMPS): per block {entry, K panel consumed, exit}
 };
 
 template <typename T, int PER16>
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane % LPR, kq = lane / LPR;
     const int D = a.D, inner = a.heads * DH;
+    unsigned long long ts0 = 0, ts1 = 0;
+    if (a.stamps) ts0 = __builtin_amdgcn_s_memrealtime();
     const int kvimg = MODE == ATT_CROSS ? img / a.kv_div : img;
     T* Kb = a.K + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
     T* Vb = a.V + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
@@ -157,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     constexpr bool V_EARLY = MODE == ATT_SELF;
     auto issue_k = [&](int base) {
 #pragma unroll
-        for (int u = 0; u < NL; ++u) rk[u] = ld16(Kb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
+        for (int u = 0; u < NL; ++u) rk[u] = ld16_stream(Kb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
         if constexpr (V_EARLY) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u) rv[u] = ld16(Vb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
+            for (int u = 0; u < NL; ++u) rv[u] = ld16_stream(Vb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
         }
     };
     issue_k(0);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
 #pragma unroll
             for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
             // the K registers of this slot are dead now: request the matching V rows into their place
-            if constexpr (!V_EARLY) rv[u] = ld16(Vb + row_off(min(key, Lm1)) + sub * PER16);
+            if constexpr (!V_EARLY) rv[u] = ld16_stream(Vb + row_off(min(key, Lm1)) + sub * PER16);
 #pragma unroll
             for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // butterfly: all LPR lanes get the dot
             d = key < L ? d : -3.0e38f;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
         do_pass(base, slot);
     }
 
+    if (a.stamps) { asm volatile("" :: "v"(acc[0])); ts1 = __builtin_amdgcn_s_memrealtime(); }
     // ---- 5. reduce over key groups (shuffles), waves (LDS), normalise, merge heads ----
 #pragma unroll
     for (int e = 0; e < PER16; ++e) {
@@ -360,6 +364,10 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
             l += p_new;
         }
         a.out[(size_t)img * inner + head * DH + tid] = Elem<T>::from_f32(o / l);
+    }
+    if (a.stamps && tid == 0) {
+        unsigned long long* d = a.stamps + 3 * (size_t)blockIdx.x;
+        d[0] = ts0; d[1] = ts1; d[2] = __builtin_amdgcn_s_memrealtime();
     }
 }
 

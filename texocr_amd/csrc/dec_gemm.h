@@ -49,6 +49,7 @@ template <typename T> struct DecGemmArgs {
     const float* resid; float* y_out; int D;    // y_out [rows][D]
     T* h_out; int F;                // [rows][F]
     float* logits;                  // [rows][N]
+    unsigned long long* stamps;     // diagnostic (TXO_STAMPS): per block {entry, operands landed, exit} in 10 ns ticks; null normally
 };
 
 constexpr int DG_BM = 16, DG_BN = 32, DG_GROUP = 8;   // DG_GROUP: k-chunks a wave keeps in flight at once
@@ -94,6 +95,8 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     const int K = a.K, rows = a.rows;
     const int row_bytes = K * (int)sizeof(T);
     const int pmask = min(16, row_bytes >> 4) - 1;
+    unsigned long long ts0 = 0, ts1 = 0;
+    if (a.stamps) ts0 = __builtin_amdgcn_s_memrealtime();
 
     // ---- epilogue operands: thread -> (row reg = wave, C/D lane = lane); fetched now, used at the end ----
     const int em = m0 + lg * 4 + wave;                        // output row of this thread
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     }
 
     // ------------------------------ cross-wave K reduction through LDS ------------------------------
+    if (a.stamps) { asm volatile("" :: "v"(acc0[0]), "v"(acc1[0])); ts1 = __builtin_amdgcn_s_memrealtime(); }
     __syncthreads();                                          // everyone is done reading the A image
     float* red = reinterpret_cast<float*>(smem);              // [wave][half][reg][lane]
 #pragma unroll
@@ -208,6 +212,10 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     for (int w = 0; w < 4; ++w) { c0 += red[((w * 2 + 0) * 4 + wave) * 64 + lane]; c1 += red[((w * 2 + 1) * 4 + wave) * 64 + lane]; }
 
     // ------------------------------ epilogue ------------------------------
+    if (a.stamps && tid == 0) {
+        unsigned long long* d = a.stamps + 3 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+        d[0] = ts0; d[1] = ts1; d[2] = __builtin_amdgcn_s_memrealtime();
+    }
     if (em >= rows) return;
     if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
         const int j = (n0 >> 1) + lr;                         // 32 interleaved weight rows -> 16 outputs

@@ -125,6 +125,14 @@ struct Engine : EngineBase {
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
+    // TXO_STAMPS=<file>: diagnostic -- every decode launch of ONE step records per-block entry / mid / exit times
+    unsigned long long* stamp_buf = nullptr; int stamp_slot = -1; static constexpr int STAMP_BLOCKS = 2048, STAMP_KERNELS = 64;
+    std::vector<std::string> stamp_names;
+    unsigned long long* next_stamp(const char* name) {
+        if (stamp_slot < 0 || stamp_slot >= STAMP_KERNELS) return nullptr;
+        stamp_names.push_back(name);
+        return stamp_buf + (size_t)(stamp_slot++) * STAMP_BLOCKS * 3;
+    }
     hipStream_t cap_stream = nullptr;      // graphs are captured here, never on the caller's stream
     hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
     int64_t* tok_buf = nullptr;            // [Bmax][Tmax] generated ids (engine-owned so graphs do not bake user pointers)
@@ -150,11 +158,32 @@ struct Engine : EngineBase {
         for (void* p : allocs) (void)hipFree(p);
     }
 
+    // All device memory of the engine comes from two arenas (workspace at create, weights at finalize), one hipMalloc
+    // each: a decode step touches ~40 small buffers and every launch starts with cold caches, so sharing large pages keeps
+    // address-translation misses off the operand round trip each dependent launch already pays.
+    struct Arena { char* base = nullptr; size_t cap = 0, off = 0; bool measuring = false; };
+    Arena arena;
     template <typename U> int dalloc(U** p, size_t n) {
+        const size_t bytes = (n * sizeof(U) + 511) & ~(size_t)255;
+        if (arena.measuring) { arena.off += bytes; *p = nullptr; return 0; }
+        if (arena.base && arena.off + bytes <= arena.cap) {
+            *p = reinterpret_cast<U*>(arena.base + arena.off);
+            arena.off += bytes;
+            return 0;
+        }
         void* q = nullptr;
-        HIP_TRY(hipMalloc(&q, n * sizeof(U) + 256));
+        HIP_TRY(hipMalloc(&q, bytes));
         allocs.push_back(q);
         *p = reinterpret_cast<U*>(q);
+        return 0;
+    }
+    int arena_begin(size_t bytes) {
+        void* q = nullptr;
+        HIP_TRY(hipMalloc(&q, bytes + (2u << 20)));
+        allocs.push_back(q);
+        arena = Arena{};
+        arena.base = reinterpret_cast<char*>(((uintptr_t)q + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));   // 2 MiB aligned
+        arena.cap = bytes;
         return 0;
     }
     int upload_f32(float** dst, const std::vector<float>& v) {
@@ -299,6 +328,11 @@ struct Engine : EngineBase {
     int finalize() override {
         if (ready) return fail(TXO_E_STATE, "weights already finalized");
         const txo_config& c = cfg;
+        {   // weights arena: fp32 size of everything handed in is an upper bound for both storage types
+            size_t bytes = 0;
+            for (auto& kv : host) bytes += kv.second.data.size() * sizeof(float) + 512;
+            if (int r = arena_begin(bytes + (1u << 20))) return r;
+        }
         const int npos = 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
         const HostTensor *t;
         if (!(t = get("encoder.cls_token", {1, 1, D}))) return TXO_E_STATE;
@@ -355,6 +389,19 @@ struct Engine : EngineBase {
     }
 
     int init() {
+        arena = Arena{}; arena.measuring = true;
+        if (int r = init_buffers()) return r;                 // pass 1: sizes only
+        if (int r = arena_begin(arena.off)) return r;
+        if (int r = init_buffers()) return r;                 // pass 2: carve
+        HIP_TRY(hipMemset(st, 0, sizeof(StepState) * MAXL));
+        max_lanes = MAXL;
+        for (int i = 1; i < max_lanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&lanes[i].own, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        return 0;
+    }
+    int init_buffers() {
         const txo_config& c = cfg;
         D = c.embed_dim; Ie = c.enc_heads * DH; Id = c.dec_heads * DH; Fe = c.enc_exp * D; Fd = c.dec_exp * D;
         V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
@@ -396,14 +443,6 @@ struct Engine : EngineBase {
         if (int r = dalloc(&bpath[1], (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&bparent, (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&btok, (size_t)Bmax * Tmax)) return r;
-        HIP_TRY(hipMemset(st, 0, sizeof(StepState) * MAXL));
-        max_lanes = MAXL;
-        if (max_lanes < 1) max_lanes = 1;
-        if (max_lanes > MAXL) max_lanes = MAXL;
-        for (int i = 1; i < max_lanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&lanes[i].own, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         return 0;
     }
 
@@ -575,6 +614,7 @@ struct Engine : EngineBase {
         const bool has_pro = PRO != PRO_NONE;
         const dim3 grid((a.N + DG_BN - 1) / DG_BN, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
+        a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : "gemm LN+logits"))) : nullptr;
         if (has_pro && a.K > 256) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12>), grid, blk, lds, s, a);
         else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4>), grid, blk, lds, s, a);
         return 0;
@@ -596,6 +636,7 @@ struct Engine : EngineBase {
         a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
         a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t;
         a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path; a.path_stride = Tmax;
+        a.stamps = (ln.nb * cfg.dec_heads <= STAMP_BLOCKS) ? next_stamp(o.cross ? "attn cross" : "attn self") : nullptr;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
         constexpr int WBS = sizeof(T) == 2 ? 3 : 1;        // self: q,k,v weight rows requested together (bf16) or one by one
@@ -704,6 +745,31 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    void dump_stamps(const char* file, hipStream_t s) {
+        const int nk = stamp_slot;
+        stamp_slot = -1;
+        std::vector<unsigned long long> h((size_t)nk * STAMP_BLOCKS * 3);
+        if (hipStreamSynchronize(s) != hipSuccess) return;
+        if (hipMemcpy(h.data(), stamp_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+        FILE* f = fopen(file, "w");
+        if (!f) return;
+        unsigned long long t0 = ~0ull;
+        for (auto v : h) if (v && v < t0) t0 = v;
+        for (int k2 = 0; k2 < nk; ++k2) {
+            unsigned long long first = ~0ull, last_in = 0, mid_lo = ~0ull, mid_hi = 0, first_out = ~0ull, last = 0; int nb = 0;
+            for (int b = 0; b < STAMP_BLOCKS; ++b) {
+                const unsigned long long* d = &h[((size_t)k2 * STAMP_BLOCKS + b) * 3];
+                if (!d[0]) continue;
+                ++nb; first = std::min(first, d[0]); last_in = std::max(last_in, d[0]); mid_lo = std::min(mid_lo, d[1]); mid_hi = std::max(mid_hi, d[1]);
+                first_out = std::min(first_out, d[2]); last = std::max(last, d[2]);
+            }
+            fprintf(f, "%-24s blocks %4d | first entry %7.2f us, last entry %7.2f | operands/panel done %7.2f .. %7.2f | first exit %7.2f, last exit %7.2f\n",
+                    stamp_names[k2].c_str(), nb, (first - t0) / 100.0, (last_in - t0) / 100.0, (mid_lo - t0) / 100.0, (mid_hi - t0) / 100.0,
+                    (first_out - t0) / 100.0, (last - t0) / 100.0);
+        }
+        fclose(f);
+    }
+
     // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
     int lane_graph(int li, int eos) {
         Lane& ln = lanes[li];
@@ -769,7 +835,12 @@ struct Engine : EngineBase {
         std::vector<int> flags((size_t)MAXL * Tmax, 0);
         const int CHUNK = 32;
         int steps = max_len;
+        const char* stamp_file = getenv("TXO_STAMPS");
+        if (stamp_file && !stamp_buf) { if (int r = dalloc(&stamp_buf, (size_t)STAMP_KERNELS * STAMP_BLOCKS * 3)) return r; }
+        const int stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
         for (int t = 0; t < max_len; ++t) {
+            if (t == stamp_step) { HIP_TRY(hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_KERNELS * STAMP_BLOCKS * 3, s)); stamp_slot = 0; stamp_names.clear(); }
+            else if (stamp_slot >= 0) dump_stamps(stamp_file, s);
             for (int i = 0; i < n_lanes; ++i) {
                 if (use_graph) HIP_TRY(hipGraphLaunch(lanes[i].exec, lanes[i].stream));
                 else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos)) return r2;
