@@ -82,8 +82,12 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
     return r * row_bytes + ((piece ^ (r & pmask)) << 4) + ((k * (int)sizeof(T)) & 15);
 }
 
-template <typename T, int PRO, int EPI, int NVMAX>
+// BN: output columns per block.  32 = two MFMA column tiles (needed by the value/gate-paired epilogues); 16 = one tile,
+// twice the blocks and half the weight bytes each block has to fetch cold (FFN-out: 96 KB -> 64 KB per block).
+template <typename T, int PRO, int EPI, int NVMAX, int BN = DG_BN>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
+    static_assert(BN == 32 || (BN == 16 && EPI != EPI_GLU_RES && EPI != EPI_GEGLU), "paired epilogues need both column tiles");
+    constexpr bool TWO = BN == 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     // masking (instead of a scalar branch) would still execute the MFMA on stale registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * DG_BN;
+    const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * BN;
     const int K = a.K, rows = a.rows;
     const int row_bytes = K * (int)sizeof(T);
     const int pmask = min(16, row_bytes >> 4) - 1;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
 #pragma unroll
         for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) {
             const int kc = wave + 4 * (g0 + c);
-            fw0[c] = ld16(w0 + kc * KCH); fw1[c] = ld16(w1 + kc * KCH);
+            fw0[c] = ld16(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16(w1 + kc * KCH);
         }
     };
     auto load_a_global = [&](int g0) {
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
                 fa[c] = ld16(smem + a_off<T>(lr, (wave + 4 * (g0 + c)) * KCH + lg * PER16, row_bytes, pmask));
         }
 #pragma unroll
-        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) { mma16<T>(acc0, fa[c], fw0[c]); mma16<T>(acc1, fa[c], fw1[c]); }
+        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) { mma16<T>(acc0, fa[c], fw0[c]); if constexpr (TWO) mma16<T>(acc1, fa[c], fw1[c]); }
     }
 
     // ------------------------------ cross-wave K reduction through LDS ------------------------------
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
         else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(v * gelu_erf(g));
     } else {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < (TWO ? 2 : 1); ++h) {
             const int n = h ? nb : na;
             const float v = h ? c1 : c0;
             if (n >= a.N) continue;

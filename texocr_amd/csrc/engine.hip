@@ -612,9 +612,17 @@ struct Engine : EngineBase {
     template <int PRO, int EPI>
     int launch_dec_gemm(hipStream_t s, DecGemmArgs<T> a) {
         const bool has_pro = PRO != PRO_NONE;
-        const dim3 grid((a.N + DG_BN - 1) / DG_BN, (a.rows + DG_BM - 1) / DG_BM), blk(256);
+        // one 16-column tile per block where the epilogue allows it and the weight slice per block is large (K >= 1024):
+        // twice the blocks, half the bytes each has to fetch cold
+        constexpr bool can_half = EPI == EPI_BIAS_RES;
+        const bool half = can_half && a.K >= 1024;
+        const int bn = half ? 16 : DG_BN;
+        const dim3 grid((a.N + bn - 1) / bn, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
         a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : "gemm LN+logits"))) : nullptr;
+        if constexpr (can_half) {
+            if (half) { hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a); return 0; }
+        }
         if (has_pro && a.K > 256) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12>), grid, blk, lds, s, a);
         else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4>), grid, blk, lds, s, a);
         return 0;
