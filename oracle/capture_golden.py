@@ -345,14 +345,16 @@ def cap_hybrid():
 
 
 def cap_tokenizer():
-    """N4: encode/decode vectors from the reference RegExTokenizer on its own vocabulary file (the data file itself
-    is copied to tests/golden/tokenizer_clean_1k.txt), and process_output (utils.py:73-79) known answers."""
-    import shutil
+    """N4: encode/decode vectors from the reference RegExTokenizer on its own vocabulary file (its merge table is
+    exported as data to tests/golden/tokenizer_vocab_1k.json), and process_output (utils.py:73-79) known answers."""
     from TeXOCR.tokenizer.tokenizer import RegExTokenizer as RefTok
     src = os.path.join(REF, "tokenizer", "tokenizer_clean_1k.txt")
-    shutil.copyfile(src, os.path.join(GOLD, "tokenizer_clean_1k.txt"))
     ref = RefTok()
     ref.load(src)
+    # the vocabulary as data (merge table extracted from the loaded reference object), not a copy of the file
+    with open(os.path.join(GOLD, "tokenizer_vocab_1k.json"), "w") as f:
+        json.dump({"vocab_size": ref.vocab_size, "special_tokens": ref.special_tokens,
+                   "merges": [[a, b, t] for (a, b), t in ref.bp_merges.items()]}, f)
     texts = [r"\int _ { 0 } ^ { 1 } x ^ 2 d x", r"\frac { \partial f } { \partial x } = \lambda \sum _ { i = 1 } ^ { n } a _ i ,",
              r"E = m c ^ 2", r"\left( \begin{array} { c c } 1 & 0 \\ 0 & 1 \end{array} \right)", "a  b\n\n c",
              "x_{12345} + 1000000", r"\alpha\beta <EOS>", "\u00e9\u03b1 \u4e2d"]

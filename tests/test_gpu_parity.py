@@ -404,7 +404,11 @@ def test_wrapper_end_to_end(tmp_path):
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(d, 3).items()}
     ckpt = tmp_path / "checkpoint_e1.pth"
     torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "epoch": 1}, ckpt)
-    cfg["tokenizer_path"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_clean_1k.txt")
+    import json
+    from texocr_amd.tokenizer import RegExTokenizer
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_vocab_1k.json")))
+    RegExTokenizer.from_tables(v["vocab_size"], v["special_tokens"], v["merges"]).save(str(tmp_path / "vocab.txt"))
+    cfg["tokenizer_path"] = str(tmp_path / "vocab.txt")
     cfg["model_path"] = str(ckpt)
     w = TeXOCRWrapper(cfg)
     assert w.model.decoder.max_len == 96                      # taken from the checkpoint's positional table

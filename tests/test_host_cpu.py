@@ -123,15 +123,23 @@ def test_sharded_generate_gloo_world2(total):
         assert np.array_equal(rows, exp_rows)
 
 
-def test_tokenizer_matches_reference_vectors():
-    """N4: vocabulary file format + byte-level BPE encode/decode against vectors produced by the reference's
-    RegExTokenizer on its own tokenizer_clean_1k.txt (data file copied under tests/golden/)."""
+def test_tokenizer_matches_reference_vectors(tmp_path):
+    """N4: byte-level BPE encode/decode against vectors produced by the reference's RegExTokenizer with its 1k vocabulary
+    (merge table exported as data by oracle/capture_golden.py), and the reference's 3-line vocabulary file format
+    (tokenizer.py:110-125) through a save()/load() round trip."""
     import json
     from texocr_amd.tokenizer import RegExTokenizer, process_output
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     g = json.load(open(os.path.join(root, "tokenizer_cases.json")))
+    v = json.load(open(os.path.join(root, "tokenizer_vocab_1k.json")))
+    tk0 = RegExTokenizer.from_tables(v["vocab_size"], v["special_tokens"], v["merges"])
+    path = tmp_path / "vocab.txt"
+    tk0.save(str(path))
+    lines = open(path).read().splitlines()
+    assert lines[0] == "1000" and lines[1].startswith("{'<PAD>': 999") and lines[2].startswith("{(115, 115): 256, (32, 95): 257")
     tk = RegExTokenizer()
-    tk.load(os.path.join(root, "tokenizer_clean_1k.txt"))
+    tk.load(str(path))
+    assert tk.bp_merges == tk0.bp_merges
     assert tk.vocab_size == g["vocab_size"] == 1000
     assert tk.special_tokens == {"<PAD>": 999, "<BOS>": 998, "<EOS>": 997} == g["special_tokens"]
     assert len(tk.bp_merges) == 741                       # 256 bytes + 741 merges + 3 specials (SURVEY section 2)

@@ -46,6 +46,14 @@ class RegExTokenizer:
             raise ValueError("malformed tokenizer file")
         self._rebuild()
 
+    @classmethod
+    def from_tables(cls, vocab_size: int, special_tokens: Dict[str, int], merges) -> "RegExTokenizer":
+        """Build from a merge table [(a, b, new_id), ...] in merge order."""
+        tk = cls(vocab_size=vocab_size, special_tokens=special_tokens)
+        tk.bp_merges = {(int(a), int(b)): int(t) for a, b, t in merges}
+        tk._rebuild()
+        return tk
+
     def save(self, path: str) -> None:
         with open(path, "w") as f:
             f.write(f"{self.vocab_size}\n{self.special_tokens}\n{self.bp_merges}\n")
