@@ -168,7 +168,7 @@ def main():
                                   "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1),
                                   "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                                                    "frac": round(enc_tf / mfma_peak, 4)}}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # reported at N=1 only (bench contract)
             result["cpu_baseline"] = cpu_baseline(dims, sd_np, a)
         print(json.dumps(result), flush=True)
     if world > 1:

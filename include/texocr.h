@@ -115,8 +115,8 @@ int txo_generate_beam(txo_engine* e, const float* img_dev, int32_t B, int32_t C,
 int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed);
 
 /* Timing hooks for bench.py: average duration (ms) of the decode-step cross-attention launches and of
- * the encoder launches recorded with HIP events on the stream the kernels run on, since the last
- * txo_profile_reset; *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,
+ * the encoder launches recorded with HIP events on the stream the kernels run on, since profiling was last
+ * enabled (txo_profile_enable(e, 1) also clears the previous samples); *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,
  * 1 = encoder (whole txo_encode), 2 = whole decode step. */
 int txo_profile_enable(txo_engine* e, int32_t on);
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count);
