@@ -86,7 +86,9 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
 // twice the blocks and half the weight bytes each block has to fetch cold (FFN-out: 96 KB -> 64 KB per block).
 template <typename T, int PRO, int EPI, int NVMAX, int BN = DG_BN>
 __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
-    static_assert(BN == 32 || (BN == 16 && EPI != EPI_GLU_RES && EPI != EPI_GEGLU), "paired epilogues need both column tiles");
+    // value/gate-paired epilogues (GLU, GeGLU) run on ONE 16-column tile whose weight rows are interleaved by 8
+    // (8 value rows, then their 8 gate rows): lane lr < 8 holds the value, lane lr + 8 the gate of output n0/2 + lr
+    constexpr bool PAIRED = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
     constexpr bool TWO = BN == 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
@@ -107,9 +109,13 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     const int emc = min(em, rows - 1);
     const int na = n0 + lr, nb = n0 + 16 + lr;                // the two 16-column tiles
     float e_b0 = 0.f, e_b1 = 0.f, e_res0 = 0.f, e_res1 = 0.f;
-    if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
-        e_b0 = a.bias[na]; e_b1 = a.bias[nb];
-        if constexpr (EPI == EPI_GLU_RES) e_res0 = a.resid[(size_t)emc * a.D + (n0 >> 1) + lr];
+    if constexpr (PAIRED) {
+        e_b0 = a.bias[na];                                    // value bias (lr < 8) or gate bias (lr >= 8) of this lane's column
+        if constexpr (TWO) e_b1 = a.bias[nb];
+        if constexpr (EPI == EPI_GLU_RES) {
+            e_res0 = a.resid[(size_t)emc * a.D + (n0 >> 1) + (lr & 7)];
+            if constexpr (TWO) e_res1 = a.resid[(size_t)emc * a.D + (n0 >> 1) + 8 + (lr & 7)];
+        }
     } else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_LOGITS) {
         e_b0 = a.bias[min(na, a.N - 1)]; e_b1 = a.bias[min(nb, a.N - 1)];
         if constexpr (EPI == EPI_BIAS_RES) { e_res0 = a.resid[(size_t)emc * a.D + na]; e_res1 = a.resid[(size_t)emc * a.D + nb]; }
@@ -220,13 +226,19 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
         unsigned long long* d = a.stamps + 3 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
         d[0] = ts0; d[1] = ts1; d[2] = __builtin_amdgcn_s_memrealtime();
     }
-    if (em >= rows) return;
-    if constexpr (EPI == EPI_GLU_RES || EPI == EPI_GEGLU) {
-        const int j = (n0 >> 1) + lr;                         // 32 interleaved weight rows -> 16 outputs
-        const float v = c0 + e_b0, g = c1 + e_b1;
-        if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = v * sigmoidf(g) + e_res0;
-        else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(v * gelu_erf(g));
+    if constexpr (PAIRED) {
+#pragma unroll
+        for (int h = 0; h < (TWO ? 2 : 1); ++h) {
+            const float mine = (h ? c1 : c0) + (h ? e_b1 : e_b0);
+            const float gate = __shfl_xor(mine, 8, 64);       // lane lr + 8 holds this output's gate (all lanes take part)
+            if (lr < 8 && em < rows) {
+                const int j = (n0 >> 1) + 8 * h + lr;         // each 16 interleaved weight rows -> 8 outputs
+                if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoidf(gate) + (h ? e_res1 : e_res0);
+                else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(mine * gelu_erf(gate));
+            }
+        }
     } else {
+        if (em >= rows) return;
 #pragma unroll
         for (int h = 0; h < (TWO ? 2 : 1); ++h) {
             const int n = h ? nb : na;

@@ -66,13 +66,14 @@ struct EngineBase {
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
 };
 
-// rows [2X][K] -> groups of 32 rows: 16 "value" rows (g*16..) followed by their 16 "gate" rows (X + g*16..)
-static std::vector<float> interleave16(const std::vector<float>& w, int X, int K) {
+// rows [2X][K] -> groups of 2G rows: G "value" rows (g*G..) followed by their G "gate" rows (X + g*G..).
+// G = 16 for the encoder GEMM (value / gate in adjacent MFMA column tiles), 8 for the decode GEMMs (both halves inside one tile)
+static std::vector<float> interleave(const std::vector<float>& w, int X, int K, int G) {
     std::vector<float> o((size_t)2 * X * K);
-    for (int g = 0; g < X / 16; ++g)
+    for (int g = 0; g < X / G; ++g)
         for (int h = 0; h < 2; ++h)
-            for (int r = 0; r < 16; ++r)
-                memcpy(&o[((size_t)g * 32 + h * 16 + r) * K], &w[((size_t)h * X + g * 16 + r) * K], sizeof(float) * K);
+            for (int r = 0; r < G; ++r)
+                memcpy(&o[((size_t)g * 2 * G + h * G + r) * K], &w[((size_t)h * X + g * G + r) * K], sizeof(float) * K);
     return o;
 }
 
@@ -231,7 +232,7 @@ struct Engine : EngineBase {
         return upload_f32(b, b0->data);
     }
 
-    int load_attn(const std::string& p, int inner, bool cross, AttnW* w, std::vector<float>* kv_concat) {
+    int load_attn(const std::string& p, int inner, bool cross, AttnW* w, std::vector<float>* kv_concat, int G) {
         const HostTensor *q = get(p + ".q.weight", {inner, D}), *k = get(p + ".k.weight", {inner, D}),
                          *v = get(p + ".v.weight", {inner, D}), *wo = get(p + ".fc_out.0.weight", {2 * D, inner}),
                          *bo = get(p + ".fc_out.0.bias", {2 * D});
@@ -246,15 +247,15 @@ struct Engine : EngineBase {
             cat.insert(cat.end(), v->data.begin(), v->data.end());
             if (int r = upload_T(&w->wqkv, cat)) return r;
         }
-        if (int r = upload_T(&w->wo, interleave16(wo->data, D, inner))) return r;
-        return upload_f32(&w->bo, interleave16(bo->data, D, 1));
+        if (int r = upload_T(&w->wo, interleave(wo->data, D, inner, G))) return r;
+        return upload_f32(&w->bo, interleave(bo->data, D, 1, G));
     }
-    int load_mlp(const std::string& p, int F, MlpW* w) {
+    int load_mlp(const std::string& p, int F, MlpW* w, int G) {
         const HostTensor *w1 = get(p + ".fc_in.fc.weight", {2 * F, D}), *b1 = get(p + ".fc_in.fc.bias", {2 * F}),
                          *w2 = get(p + ".fc_out.weight", {D, F}), *b2 = get(p + ".fc_out.bias", {D});
         if (!w1 || !b1 || !w2 || !b2) return TXO_E_STATE;
-        if (int r = upload_T(&w->w1, interleave16(w1->data, F, D))) return r;
-        if (int r = upload_f32(&w->b1, interleave16(b1->data, F, 1))) return r;
+        if (int r = upload_T(&w->w1, interleave(w1->data, F, D, G))) return r;
+        if (int r = upload_f32(&w->b1, interleave(b1->data, F, 1, G))) return r;
         if (int r = upload_T(&w->w2, w2->data)) return r;
         return upload_f32(&w->b2, b2->data);
     }
@@ -353,8 +354,8 @@ struct Engine : EngineBase {
         enc_attn.resize(c.enc_layers); enc_mlp.resize(c.enc_layers);
         for (int l = 0; l < c.enc_layers; ++l) {
             const std::string p = "encoder.attn_layers.layers.";
-            if (int r = load_attn(p + std::to_string(2 * l) + ".1", Ie, false, &enc_attn[l], nullptr)) return r;
-            if (int r = load_mlp(p + std::to_string(2 * l + 1) + ".1", Fe, &enc_mlp[l])) return r;
+            if (int r = load_attn(p + std::to_string(2 * l) + ".1", Ie, false, &enc_attn[l], nullptr, 16)) return r;
+            if (int r = load_mlp(p + std::to_string(2 * l + 1) + ".1", Fe, &enc_mlp[l], 16)) return r;
         }
         if (!(t = get("encoder.norm.weight", {D}))) return TXO_E_STATE;
         if (int r = upload_f32(&encn_g, t->data)) return r;
@@ -370,9 +371,9 @@ struct Engine : EngineBase {
         std::vector<float> kv_concat;
         for (int l = 0; l < c.dec_layers; ++l) {
             const std::string p = "decoder.net.attn_layers.layers.";
-            if (int r = load_attn(p + std::to_string(3 * l) + ".1", Id, false, &dec_self[l], nullptr)) return r;
-            if (int r = load_attn(p + std::to_string(3 * l + 1) + ".1", Id, true, &dec_cross[l], &kv_concat)) return r;
-            if (int r = load_mlp(p + std::to_string(3 * l + 2) + ".1", Fd, &dec_mlp[l])) return r;
+            if (int r = load_attn(p + std::to_string(3 * l) + ".1", Id, false, &dec_self[l], nullptr, 8)) return r;
+            if (int r = load_attn(p + std::to_string(3 * l + 1) + ".1", Id, true, &dec_cross[l], &kv_concat, 8)) return r;
+            if (int r = load_mlp(p + std::to_string(3 * l + 2) + ".1", Fd, &dec_mlp[l], 8)) return r;
         }
         if (int r = upload_T(&wckv, kv_concat)) return r;
         if (!(t = get("decoder.net.norm.weight", {D}))) return TXO_E_STATE;
@@ -611,20 +612,26 @@ struct Engine : EngineBase {
 
     template <int PRO, int EPI>
     int launch_dec_gemm(hipStream_t s, DecGemmArgs<T> a) {
-        const bool has_pro = PRO != PRO_NONE;
-        // one 16-column tile per block where the epilogue allows it and the weight slice per block is large (K >= 1024):
-        // twice the blocks, half the bytes each has to fetch cold
-        constexpr bool can_half = EPI == EPI_BIAS_RES;
-        const bool half = can_half && a.K >= 1024;
+        constexpr bool has_pro = PRO != PRO_NONE;
+        // 16-column tiles (half the cold weight bytes per block, twice the blocks) where the block's traffic is its weight
+        // slice: the out-projections and FFN-out (K >= 1024).  Launches with an LN prologue keep 32 columns: every block also
+        // fetches the 16 rows of y, so more blocks only multiply that traffic (measured: FFN-in 3.9 -> 7 us at 16 columns).
+        constexpr bool paired = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
+        const bool half = (paired && !has_pro) || (EPI == EPI_BIAS_RES && a.K >= 1024);
         const int bn = half ? 16 : DG_BN;
         const dim3 grid((a.N + bn - 1) / bn, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
         a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : "gemm LN+logits"))) : nullptr;
-        if constexpr (can_half) {
-            if (half) { hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a); return 0; }
+        const bool big = has_pro && a.K > 256;
+        if constexpr (paired && !has_pro) {
+            hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a);
+        } else if constexpr (EPI == EPI_BIAS_RES) {
+            if (half) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a);
+            else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 32>), grid, blk, lds, s, a);
+        } else {
+            if (big) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12, 32>), grid, blk, lds, s, a);
+            else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 32>), grid, blk, lds, s, a);
         }
-        if (has_pro && a.K > 256) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12>), grid, blk, lds, s, a);
-        else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4>), grid, blk, lds, s, a);
         return 0;
     }
 
