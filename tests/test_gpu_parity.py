@@ -450,3 +450,31 @@ def test_beam_search_extension():
         m.generate(img.cuda(), 24, beam=9)
     with pytest.raises(ValueError):
         m.generate(torch.rand(5, 3, 64, 96, device="cuda"), 24, beam=3)       # 15 rows > max_batch 12
+
+
+def test_multipass_attention_panels():
+    """Panels longer than one register pass: a full 448x448 canvas (N = 785 encoder tokens -> several cross-attention passes
+    per launch in both storage types) and a positional table of 300 (> 256 cached self-attention keys -> two passes)."""
+    cpu_ref = _oracle()
+    d = Dims(canvas=448, embed_dim=64, enc_heads=2, enc_layers=1, dec_heads=2, dec_layers=2, vocab=96, max_len=300,
+             bos=94, eos=93, pad=95)
+    d, sd, m = build(d, seed=11, max_batch=2)
+    img = torch.from_numpy(synth.synth_images(2, 3, 448, 448, seed=51))
+    sdt = cpu_ref.to_torch_sd(sd)
+    enc_ref = cpu_ref.encode(sdt, img)
+    enc = m.encoder(img.cuda())
+    assert enc.shape == (2, 785, 64)
+    assert float((enc.cpu() - enc_ref).abs().max()) < 1e-4
+    m.eos_token = None
+    ref_t, ref_l = cpu_ref.generate_cached(sdt, img, d.bos, None, 290, collect_logits=True, enc=enc_ref)
+    toks, logits = m.generate(img.cuda(), 290, return_logits=True)
+    assert toks.shape == (2, 290)
+    assert_tokens_exact_up_to_margin(toks.cpu().numpy(), ref_t.numpy(), ref_l)
+    if bool((toks.cpu() == ref_t).all()):
+        assert float((logits.cpu() - ref_l).abs().max()) < 1e-3
+    # bf16 engine: teacher-forced on the fp32 tokens, logits stay close through all passes
+    d2, sd2, mb = build(d, seed=11, dtype="bf16", max_batch=2)
+    encb = mb.encoder(img.cuda())
+    prefix = torch.cat([torch.full((2, 1), d.bos, dtype=torch.long, device="cuda"), toks[:, :-1]], 1)
+    lb = mb.decoder.net(prefix[:, :280], enc=encb).cpu()
+    assert float((lb - ref_l[:, :280]).abs().max()) < 0.3
