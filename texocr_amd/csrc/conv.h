@@ -14,6 +14,7 @@
 // deterministic (fixed reduction order, no float atomics).  Bound: MFMA for the convs, HBM for the norms.
 #pragma once
 #include "common.h"
+#include "gemm_big.h"
 
 namespace txo {
 
@@ -63,9 +64,13 @@ template <typename T> struct LoadStem {
 struct EpiTokens {
     float* x; const float* bias; const float* pos; int D, hw, w, Gw;
     static constexpr bool PAIRED = false;
-    __device__ inline void operator()(int m, int n, float v) const {
+    __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
-        x[((size_t)b * (hw + 1) + 1 + p) * D + n] = v + bias[n] + pos[(size_t)(1 + pr * Gw + pc) * D + n];
+        float bb[8], pp[8];
+        load8(bias + n, bb); load8(pos + (size_t)(1 + pr * Gw + pc) * D + n, pp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e] + pp[e];
+        store8<float>(x + ((size_t)b * (hw + 1) + 1 + p) * D + n, v);
     }
 };
 

@@ -45,54 +45,88 @@ template <typename T> struct LoadPatch {
     }
 };
 
-// ---------------- epilogues: called once per (16-row, 16/32-col) accumulator group ---------------
-// Each gets (m, n, v) for plain tiles or (m, j, value, gate) for interleaved GLU pairs.
-template <typename T> struct EpiStore {           // out[m][n] = acc (+ bias)
+// ---------------- epilogues ----------------------------------------------------------------------------------
+// The accumulator tile is staged through LDS and handed to the epilogue as 8 consecutive columns of one row
+// (plain: v[8] at columns n..n+7; paired: value v[8] and gate g[8] of outputs j..j+7), so every global access is a
+// 16- or 32-byte row segment instead of a 2-4 byte element of the MFMA register layout.
+template <typename TO> __device__ inline void store8(TO* p, const float (&v)[8]) {
+    if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        union { bf16 h[8]; u32x4 u; } c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c.h[e] = __float2bfloat16(v[e]);
+        st16(p, c.u);
+    }
+}
+__device__ inline void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
     T* out; int ldo; const float* bias;
     static constexpr bool PAIRED = false;
-    __device__ inline void operator()(int m, int n, float v) const {
-        if (bias) v += bias[n];
-        out[(size_t)m * ldo + n] = Elem<T>::from_f32(v);
+    __device__ inline void operator()(int m, int n, float (&v)[8]) const {
+        if (bias) { float b[8]; load8(bias + n, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e]; }
+        store8<T>(out + (size_t)m * ldo + n, v);
     }
 };
 template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
     T* base; size_t which_stride; int inner, heads, ntok;
     static constexpr bool PAIRED = false;
-    __device__ inline void operator()(int m, int n, float v) const {
-        int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;
-        int b = m / ntok, t = m - b * ntok;
-        base[which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d] = Elem<T>::from_f32(v);
+    __device__ inline void operator()(int m, int n, float (&v)[8]) const {
+        const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
+        const int b = m / ntok, t = m - b * ntok;
+        store8<T>(base + which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d, v);
     }
 };
-struct EpiGluRes {                                // y[m][j] = (v+bv) * sigmoid(g+bg) + resid[m][j]   (fp32 stream)
+struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoid(g+bg) + resid[m][j..]   (fp32 stream)
     float* y; const float* resid; const float* bias; int D;   // bias is in the interleaved order
     static constexpr bool PAIRED = true;
-    __device__ inline void operator()(int m, int j, int nv, int ng, float v, float g) const {
-        v += bias[nv]; g += bias[ng];
-        y[(size_t)m * D + j] = v * sigmoidf(g) + resid[(size_t)m * D + j];
+    __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
+        float bv[8], bg[8], r[8];
+        load8(bias + nv, bv); load8(bias + ng, bg); load8(resid + (size_t)m * D + j, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoidf(g[e] + bg[e]) + r[e];
+        store8<float>(y + (size_t)m * D + j, v);
     }
 };
-template <typename T> struct EpiGeglu {           // h[m][j] = (v+bv) * gelu(g+bg)
+template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
     T* h; const float* bias; int F;
     static constexpr bool PAIRED = true;
-    __device__ inline void operator()(int m, int j, int nv, int ng, float v, float g) const {
-        v += bias[nv]; g += bias[ng];
-        h[(size_t)m * F + j] = Elem<T>::from_f32(v * gelu_erf(g));
+    __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
+        float bv[8], bg[8];
+        load8(bias + nv, bv); load8(bias + ng, bg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_erf(g[e] + bg[e]);
+        store8<T>(h + (size_t)m * F + j, v);
     }
 };
-struct EpiBiasRes {                               // y[m][n] = acc + bias[n] + resid[m][n]
+struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
     float* y; const float* resid; const float* bias; int D;
     static constexpr bool PAIRED = false;
-    __device__ inline void operator()(int m, int n, float v) const {
-        y[(size_t)m * D + n] = v + bias[n] + resid[(size_t)m * D + n];
+    __device__ inline void operator()(int m, int n, float (&v)[8]) const {
+        float b[8], r[8];
+        load8(bias + n, b); load8(resid + (size_t)m * D + n, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e] + r[e];
+        store8<float>(y + (size_t)m * D + n, v);
     }
 };
-struct EpiPatch {                                 // x[b][1+p][n] = acc + bias[n] + pos[1 + pr*G + pc][n]
+struct EpiPatch {                                 // x[b][1+p][n..] = acc + bias + pos[1 + pr*G + pc][n..]
     float* x; const float* bias; const float* pos; int D, hw, w, G;
     static constexpr bool PAIRED = false;
-    __device__ inline void operator()(int m, int n, float v) const {
-        int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
-        x[((size_t)b * (hw + 1) + 1 + p) * D + n] = v + bias[n] + pos[(size_t)(1 + pr * G + pc) * D + n];
+    __device__ inline void operator()(int m, int n, float (&v)[8]) const {
+        const int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
+        float bb[8], pp[8];
+        load8(bias + n, bb); load8(pos + (size_t)(1 + pr * G + pc) * D + n, pp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bb[e] + pp[e];
+        store8<float>(x + ((size_t)b * (hw + 1) + 1 + p) * D + n, v);
     }
 };
 
@@ -170,26 +204,40 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_big_kernel(ALoad aload, const
         __syncthreads();
     }
 
-    // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+    // ---- epilogue: accumulators -> LDS tile [128][128] f32 (reuses the staging buffers: exactly 64 KB) -> row segments.
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + reg.  Column XOR by 16 on odd 4-row groups keeps the 4-byte LDS
+    // writes at the inherent 2 lanes per bank; 8-column groups stay contiguous for the row-wise reads.
+    float* tile = reinterpret_cast<float*>(&lds[0][0][0]);
+    auto tidx = [](int row, int col) { return row * GB_BN + (col ^ (((row >> 2) & 1) << 4)); };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wm + 16 * i + lg * 4 + r;
-            if (m >= M) continue;
-            if constexpr (Epi::PAIRED) {
-                // columns interleaved in groups of 16: [16 value | 16 gate] per 32 weight rows
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    const int nv = n0 + wn + 32 * jp + lr, ng = nv + 16;
-                    if (ng < N) epi(m, (nv >> 5) * 16 + lr, nv, ng, acc[i][2 * jp][r], acc[i][2 * jp + 1][r]);
-                }
-            } else {
+            for (int r = 0; r < 4; ++r) tile[tidx(wm + 16 * i + lg * 4 + r, wn + 16 * j + lr)] = acc[i][j][r];
+    __syncthreads();
+    if constexpr (Epi::PAIRED) {
+        // columns interleaved in groups of 16: [16 value | 16 gate] per 32 weight rows -> 8 value groups of 8 per row
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + wn + 16 * j + lr;
-                    if (n < N) epi(m, n, acc[i][j][r]);
-                }
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + GB_THREADS * q, row = idx >> 3, vg = idx & 7;       // vg: value group within the row
+            const int cv = (vg >> 1) * 32 + (vg & 1) * 8, m = m0 + row;
+            const int nv = n0 + cv, ng = nv + 16;
+            if (m < M && ng + 7 < N) {
+                float v[8], g[8];
+                load8(&tile[tidx(row, cv)], v); load8(&tile[tidx(row, cv + 16)], g);
+                epi(m, (nv >> 5) * 16 + (nv & 15), nv, ng, v, g);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int idx = tid + GB_THREADS * q, row = idx >> 4, cg = idx & 15;
+            const int m = m0 + row, n = n0 + cg * 8;
+            if (m < M && n + 7 < N) {
+                float v[8];
+                load8(&tile[tidx(row, cg * 8)], v);
+                epi(m, n, v);
             }
         }
     }
@@ -199,6 +247,7 @@ template <typename T, class ALoad, class Epi>
 inline void launch_gemm_big(hipStream_t s, ALoad aload, const T* W, int M, int N, int K, Epi epi) {
     const int tiles_m = (M + GB_BM - 1) / GB_BM, tiles_n = (N + GB_BN - 1) / GB_BN;
     const int n_tiles = tiles_m * tiles_n;
+    // the epilogue hands out 8-column row segments: every N on this path is a multiple of 8 (64-wide heads, 16-interleave)
     hipLaunchKernelGGL((gemm_big_kernel<T, ALoad, Epi>), dim3(n_tiles), dim3(GB_THREADS), 0, s, aload, W, M, N, K,
                        tiles_n, n_tiles, epi);
 }
