@@ -82,23 +82,31 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
     return r * row_bytes + ((piece ^ (r & pmask)) << 4) + ((k * (int)sizeof(T)) & 15);
 }
 
-// BN: output columns per block.  32 = two MFMA column tiles (needed by the value/gate-paired epilogues); 16 = one tile,
-// twice the blocks and half the weight bytes each block has to fetch cold (FFN-out: 96 KB -> 64 KB per block).
-template <typename T, int PRO, int EPI, int NVMAX, int BN = DG_BN>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
+// BN: output columns per block.  32 = two MFMA column tiles; 16 = one tile, twice the blocks and half the weight bytes
+// each block has to fetch cold (FFN-out: 96 KB -> 64 KB per block).
+// KW: 64-byte k-chunks per wave when K is known at compile time (K = KW * 4 chunks), 0 = any K.  With KW fixed every
+// fragment array has its exact size and every loop unrolls without guards: the run-time-K form of the LN-prologue
+// variants compiled to 110 branches and 324 VGPRs (one block per CU -- the 1024 blocks of the FFN-in launch at batch
+// 256 ran in four rounds, 17 us); the fixed form is straight-line code at <= 128 VGPRs.
+template <typename T, int PRO, int EPI, int KW, int BN = DG_BN>
+__global__ __launch_bounds__(256, (KW > 0 && KW <= 8 && (PRO == PRO_NONE || KW * 4 * Elem<T>::KCHUNK <= 256) ? 4 : 2))
+void dec_gemm_kernel(DecGemmArgs<T> a) {
     // value/gate-paired epilogues (GLU, GeGLU) run on ONE 16-column tile whose weight rows are interleaved by 8
     // (8 value rows, then their 8 gate rows): lane lr < 8 holds the value, lane lr + 8 the gate of output n0/2 + lr
     constexpr bool PAIRED = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
     constexpr bool TWO = BN == 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
+    constexpr bool FIXED = KW > 0;
+    constexpr int GROUP = FIXED ? KW : DG_GROUP;              // k-chunks a wave keeps in flight at once
+    constexpr int NVMAX = FIXED ? (KW * 4 * KCH) / 64 : 12;   // LN prologue: float4 per lane per row (row length 64 * nv)
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave id must be PROVABLY wave-uniform: MFMA ignores EXEC, so a guard the compiler lowers to EXEC
     // masking (instead of a scalar branch) would still execute the MFMA on stale registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
     const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * BN;
-    const int K = a.K, rows = a.rows;
+    const int K = FIXED ? KW * 4 * KCH : a.K, rows = a.rows;
     const int row_bytes = K * (int)sizeof(T);
     const int pmask = min(16, row_bytes >> 4) - 1;
     unsigned long long ts0 = 0, ts1 = 0;
@@ -125,14 +133,14 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
 
     // ---- weight fragments of the first group: issued before the prologue so they fly under it ----
     const int nch = K / KCH;                                  // 64-byte k-chunks per row
-    const int my_nch = (nch - wave + 3) >> 2;                 // chunks wave, wave+4, ...
+    const int my_nch = FIXED ? KW : (nch - wave + 3) >> 2;    // chunks wave, wave+4, ...
     const int wr0 = min(na, a.N - 1), wr1 = min(nb, a.N - 1);
     const T* w0 = a.W + (size_t)wr0 * K + lg * PER16;
     const T* w1 = a.W + (size_t)wr1 * K + lg * PER16;
-    u32x4 fw0[DG_GROUP], fw1[DG_GROUP], fa[DG_GROUP];
+    u32x4 fw0[GROUP], fw1[GROUP], fa[GROUP];
     auto load_w = [&](int g0) {
 #pragma unroll
-        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) {
+        for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch) {
             const int kc = wave + 4 * (g0 + c);
             fw0[c] = ld16(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16(w1 + kc * KCH);
         }
@@ -140,15 +148,18 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
     auto load_a_global = [&](int g0) {
         const int m = min(m0 + lr, rows - 1);
 #pragma unroll
-        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch)
+        for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
             fa[c] = ld16(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
     };
     load_w(0);
     if constexpr (PRO == PRO_NONE) load_a_global(0);
+    // keep every fragment load ahead of the first MFMA: with K fixed this is one basic block and the machine
+    // scheduler would otherwise interleave loads and MFMAs four at a time (serialising the memory latency)
+    __builtin_amdgcn_sched_barrier(0);
 
     // ------------------------------ prologue: 16 normalised rows -> LDS ------------------------------
     if constexpr (PRO != PRO_NONE) {
-        const int sub = tid & 15, r = tid >> 4, nv = K >> 6;
+        const int sub = tid & 15, r = tid >> 4, nv = FIXED ? NVMAX : K >> 6;
         const float inv_d = 1.0f / K;
         const int m = min(m0 + r, rows - 1);
         float4 v[NVMAX], g[NVMAX], b[NVMAX];
@@ -197,15 +208,15 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs<T> a) {
 
     // ------------------------------ main: wave w owns k-chunks w, w+4, ... ------------------------------
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    for (int g0 = 0; g0 < my_nch; g0 += DG_GROUP) {
+    for (int g0 = 0; g0 < my_nch; g0 += GROUP) {
         if (g0 > 0) { load_w(g0); if constexpr (PRO == PRO_NONE) load_a_global(g0); }
         if constexpr (PRO != PRO_NONE) {
 #pragma unroll
-            for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch)
+            for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
                 fa[c] = ld16(smem + a_off<T>(lr, (wave + 4 * (g0 + c)) * KCH + lg * PER16, row_bytes, pmask));
         }
 #pragma unroll
-        for (int c = 0; c < DG_GROUP; ++c) if (g0 + c < my_nch) { mma16<T>(acc0, fa[c], fw0[c]); if constexpr (TWO) mma16<T>(acc1, fa[c], fw1[c]); }
+        for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch) { mma16<T>(acc0, fa[c], fw0[c]); if constexpr (TWO) mma16<T>(acc1, fa[c], fw1[c]); }
     }
 
     // ------------------------------ cross-wave K reduction through LDS ------------------------------

@@ -622,16 +622,27 @@ struct Engine : EngineBase {
         const dim3 grid((a.N + bn - 1) / bn, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
         a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : "gemm LN+logits"))) : nullptr;
-        const bool big = has_pro && a.K > 256;
-        if constexpr (paired && !has_pro) {
-            hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a);
-        } else if constexpr (EPI == EPI_BIAS_RES) {
-            if (half) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 16>), grid, blk, lds, s, a);
-            else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 32>), grid, blk, lds, s, a);
+        // K known at compile time for the shapes of the reference configurations (straight-line code, exact register
+        // arrays); any other K takes the run-time form (KW = 0)
+        constexpr int KCH = Elem<T>::KCHUNK;
+        const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
+#define TXO_DG(KW_, BN_) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, KW_, BN_>), grid, blk, lds, s, a)
+        if constexpr ((paired && !has_pro) || EPI == EPI_BIAS_RES) {
+            if (half) {
+                switch (kw) {
+                    case 4: TXO_DG(4, 16); break;    case 6: TXO_DG(6, 16); break;    case 8: TXO_DG(8, 16); break;
+                    case 12: TXO_DG(12, 16); break;  case 16: TXO_DG(16, 16); break;  default: TXO_DG(0, 16);
+                }
+            } else {
+                TXO_DG(0, 32);
+            }
         } else {
-            if (big) hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 12, 32>), grid, blk, lds, s, a);
-            else hipLaunchKernelGGL((dec_gemm_kernel<T, PRO, EPI, 4, 32>), grid, blk, lds, s, a);
+            switch (kw) {
+                case 2: TXO_DG(2, 32); break;  case 4: TXO_DG(4, 32); break;  case 6: TXO_DG(6, 32); break;
+                default: TXO_DG(0, 32);
+            }
         }
+#undef TXO_DG
         return 0;
     }
 
