@@ -32,6 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--settle-seconds", type=float, default=1.5,
+                    help="untimed: repeat the step for this long before the W warmup steps so that a freshly started GPU "
+                         "reaches its steady clocks (the first process on a fresh box measured 8 %% slower without it)")
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=224)
     ap.add_argument("--width", type=int, default=672)
@@ -97,6 +100,10 @@ def main():
             raise RuntimeError(f"expected {a.max_len} decode steps, got {toks.shape[1]}")
         return all_gather_rows(toks, counts) if world > 1 else toks
 
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < a.settle_seconds:
+        step(0)
+        torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
