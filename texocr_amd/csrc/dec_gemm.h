@@ -42,6 +42,7 @@ template <typename T> struct DecGemmArgs {
     const float* gamma; const float* beta;
     const int64_t* tok; const float* tok_emb; const float* pos_emb;   // PRO_EMBED
     const int* t_ptr;               // decode position (device)
+    int t_host;                     // >= 0: the position, known to the host (eager launches) -- saves the dependent scalar load; -1: read *t_ptr (graph replay)
     // epilogue
     float* q_out;                   // [rows][inner] fp32
     T* k_cache; T* v_cache;         // [rows*heads][tmax][64]
@@ -129,7 +130,7 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
         if constexpr (EPI == EPI_BIAS_RES) { e_res0 = a.resid[(size_t)emc * a.D + na]; e_res1 = a.resid[(size_t)emc * a.D + nb]; }
     }
     int t = 0;
-    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = *a.t_ptr;
+    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
 
     // ---- weight fragments of the first group: issued before the prologue so they fly under it ----
     const int nch = K / KCH;                                  // 64-byte k-chunks per row

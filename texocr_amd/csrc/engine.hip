@@ -126,6 +126,7 @@ struct Engine : EngineBase {
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
+    int step_host_t = -1;             // position of the step being enqueued when the host knows it (see enqueue_step)
     // TXO_STAMPS=<file>: diagnostic -- every decode launch of ONE step records per-block entry / mid / exit times
     unsigned long long* stamp_buf = nullptr; int stamp_slot = -1; static constexpr int STAMP_BLOCKS = 2048, STAMP_KERNELS = 64;
     std::vector<std::string> stamp_names;
@@ -660,7 +661,7 @@ struct Engine : EngineBase {
         a.y = dy + r0 * D; a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = o.x_out;
         a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = o.W;
         a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
-        a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t;
+        a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t; a.t_host = step_host_t;
         a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path; a.path_stride = Tmax;
         a.stamps = (ln.nb * cfg.dec_heads <= STAMP_BLOCKS) ? next_stamp(o.cross ? "attn cross" : "attn self") : nullptr;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
@@ -693,15 +694,18 @@ struct Engine : EngineBase {
     }
 
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
+    // host_t: the decode position when the caller knows it (every eager loop does); -1 makes the kernels read the
+    // device-side counter instead, which is what lets ONE captured graph serve every step
     int enqueue_step(hipStream_t s, int li, int64_t* tokens_out, int out_stride, float* logits_out, int eos,
-                     const BeamCtx* bm = nullptr) {
+                     const BeamCtx* bm = nullptr, int host_t = -1) {
+        step_host_t = host_t;
         const Lane& ln = lanes[li];
         const int B = sB, N = sN, nb = ln.nb;
         const size_t r0 = ln.b0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
         DecGemmArgs<T> base{};
-        base.rows = nb; base.gamma = dec_g; base.beta = dec_b; base.t_ptr = &st[li].t; base.D = D;
+        base.rows = nb; base.gamma = dec_g; base.beta = dec_b; base.t_ptr = &st[li].t; base.t_host = host_t; base.D = D;
         base.inner = Id; base.heads = cfg.dec_heads; base.tmax = Tmax;
         float* lx = dx + r0 * D; float* ly = dy + r0 * D; T* lao = dao + r0 * Id; T* lhid = dhid + r0 * Fd;
         float* llog = dlogits + r0 * V;
@@ -822,7 +826,7 @@ struct Engine : EngineBase {
         lanes[0].stream = s;
         if (tok_in) HIP_TRY(hipMemcpyAsync(cur_tok, tok_in, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
         hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, t);
-        if (int r = enqueue_step(s, 0, nullptr, 0, nullptr, -1)) return r;
+        if (int r = enqueue_step(s, 0, nullptr, 0, nullptr, -1, nullptr, t)) return r;
         if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, dlogits, sizeof(float) * sB * V, hipMemcpyDeviceToDevice, s));
         if (tok_out) HIP_TRY(hipMemcpyAsync(tok_out, cur_tok, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipGetLastError());
@@ -869,7 +873,7 @@ struct Engine : EngineBase {
             else if (stamp_slot >= 0) dump_stamps(stamp_file, s);
             for (int i = 0; i < n_lanes; ++i) {
                 if (use_graph) HIP_TRY(hipGraphLaunch(lanes[i].exec, lanes[i].stream));
-                else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos)) return r2;
+                else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos, nullptr, t)) return r2;
             }
             if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
                 const int lo = (t / CHUNK) * CHUNK;
@@ -924,7 +928,7 @@ struct Engine : EngineBase {
         const int CHUNK = 32;
         for (int t = 0; t < max_len; ++t) {
             BeamCtx bm{beams, bpath[cur], bpath[cur ^ 1]};
-            if (int r2 = enqueue_step(s, 0, nullptr, 0, nullptr, eos, &bm)) return r2;
+            if (int r2 = enqueue_step(s, 0, nullptr, 0, nullptr, eos, &bm, t)) return r2;
             cur ^= 1;
             if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
                 const int lo = (t / CHUNK) * CHUNK;
