@@ -478,3 +478,31 @@ def test_multipass_attention_panels():
     prefix = torch.cat([torch.full((2, 1), d.bos, dtype=torch.long, device="cuda"), toks[:, :-1]], 1)
     lb = mb.decoder.net(prefix[:, :280], enc=encb).cpu()
     assert float((lb - ref_l[:, :280]).abs().max()) < 0.3
+
+
+def test_large_ragged_batch_rows_independent():
+    """More decode rows than one launch round of 16-row tiles at the config.yml widths, ragged (130 rows: nine tiles, the
+    last one with 2 rows): fp32 vs the oracle, and in both storage types the rows of the 130-row run must equal the same
+    images decoded in 64-row runs bit for bit (a row's arithmetic never depends on the batch around it)."""
+    cpu_ref = _oracle()
+    d = Dims(canvas=64, max_len=16)
+    img = torch.from_numpy(synth.synth_images(130, 3, 32, 64, seed=77))
+    d, sd, m = build(d, seed=21, max_batch=130)
+    sdt = cpu_ref.to_torch_sd(sd)
+    m.eos_token = None
+    ref_t, ref_l = cpu_ref.generate_cached(sdt, img, d.bos, None, 12, collect_logits=True)
+    toks, logits = m.generate(img.cuda(), 12, return_logits=True)
+    assert toks.shape == (130, 12)
+    assert_tokens_exact_up_to_margin(toks.cpu().numpy(), ref_t.numpy(), ref_l)
+    if bool((toks.cpu() == ref_t).all()):
+        assert float((logits.cpu() - ref_l).abs().max()) < 1e-3
+    for dtype in ("fp32", "bf16"):
+        _, _, mm = build(d, seed=21, dtype=dtype, max_batch=130)
+        mm.eos_token = None
+        big_t, big_l = mm.generate(img.cuda(), 12, return_logits=True)
+        small_t, small_l = mm.generate(img[:64].cuda(), 12, return_logits=True)
+        assert torch.equal(big_t[:64], small_t), dtype
+        assert torch.equal(big_l[:64], small_l), dtype
+        tail_t, tail_l = mm.generate(img[66:].cuda(), 12, return_logits=True)      # rows 66..129 as a 64-row batch
+        assert torch.equal(big_t[66:], tail_t), dtype
+        assert torch.equal(big_l[66:], tail_l), dtype
