@@ -101,8 +101,8 @@ def main():
         return all_gather_rows(toks, counts) if world > 1 else toks
 
     t_settle = time.perf_counter()
-    while time.perf_counter() - t_settle < a.settle_seconds:
-        step(0)
+    while time.perf_counter() - t_settle < a.settle_seconds:      # local work only: ranks may run different counts
+        model.generate(imgs[0], a.max_len)
         torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
