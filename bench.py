@@ -113,6 +113,10 @@ def main():
     t0 = time.perf_counter()
     lat = []
     for i in range(a.steps):
+        if i == a.steps - 1 and not a.no_roofline and rank == 0:
+            # the cross-attention dispatches of the LAST timed step carry HIP events (bound to the dispatch, no extra commands
+            # on the stream).  Only one step: event-carrying launches cost 9 % of a step's wall time, which `value` must not pay K times.
+            eng.profile(2)
         s0 = time.perf_counter()
         out = step(i)
         torch.cuda.synchronize()
@@ -147,7 +151,8 @@ def main():
                        "all-gather of token ids)"},
         }
         if not a.no_roofline:
-            eng.profile(True)
+            ms_live, n_live = eng.profile_read(0)          # measured over the timed region above
+            eng.profile(True)                               # separate pass: encoder and whole-step spans (marker commands)
             model.generate(imgs[0], a.max_len)
             torch.cuda.synchronize()
             ms, n = eng.profile_read(0)
@@ -167,11 +172,16 @@ def main():
             enc_flop = a.batch * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
             mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3          # dense TFLOP/s, MI355X_MICROARCH.md
             enc_tf = enc_flop / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
+            ms_pass, n_pass = ms, n
+            if n_live > 0:
+                ms, n = ms_live, n_live
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
                                   "traffic": traffic, "algorithmic_bytes_per_launch": algo,
                                   "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
+                                  "timed_over": "the last of the K timed steps (dispatch-bound HIP events)" if n_live > 0 else "separate profiled pass",
+                                  "avg_launch_us_profiled_pass": round(ms_pass * 1e3, 2),
                                   "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1),
                                   "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                                                    "frac": round(enc_tf / mfma_peak, 4)}}

@@ -143,7 +143,9 @@ struct Engine : EngineBase {
     float* bscore = nullptr; int* bfin = nullptr; short* bpath[2] = {nullptr, nullptr}; short* bparent = nullptr; int* btok = nullptr;
     struct BeamCtx { int k; const short* path_cur; short* path_nxt; };
     // ----- profiling -----
-    bool prof = false; EventPool pool;
+    bool prof = false;                // full: per-launch cross-attention events + markers around every encode and step
+    bool prof_cross = false;          // light: only the cross-attention dispatches carry events (no extra packets)
+    EventPool pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_cross, ev_enc, ev_step;
 
     int D, Ie, Id, Fe, Fd, V, Tmax, Nmax, Bmax;
@@ -670,7 +672,8 @@ struct Engine : EngineBase {
         // profiling: hipExtLaunchKernelGGL binds the start/stop events to the dispatch itself (the kernel's own begin /
         // end timestamps, what rocprofv3 reports), not to marker commands around it
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = prof && o.cross;
+        // light mode never creates events inside a timed region: it records until the pre-created pool is used up
+        const bool timed = o.cross && (prof || (prof_cross && pool.used + 2 <= pool.ev.size()));
         if (timed) { e0 = pool.next(); e1 = pool.next(); }
         const bool narrow = (D & 255) != 0;
 #define TXO_DA1(MODE, APRO, NLV, WBV, NARROW)                                                                         \
@@ -956,8 +959,12 @@ struct Engine : EngineBase {
     }
 
     int profile_enable(int on) override {
-        prof = on != 0;
+        prof = on == 1; prof_cross = on == 2;
         ev_cross.clear(); ev_enc.clear(); ev_step.clear(); pool.used = 0;
+        if (prof_cross) {           // events for 16 generate() calls, created now
+            const size_t want = (size_t)16 * 2 * cfg.dec_layers * Tmax;
+            while (pool.ev.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); pool.ev.push_back(e); }
+        }
         return 0;
     }
     int profile_read(int kind, double* avg_ms, int64_t* count) override {

@@ -189,8 +189,9 @@ class HipEngine:
         _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
 
     # profiling hooks used by bench.py
-    def profile(self, on: bool) -> None:
-        _lib.check(self.lib.txo_profile_enable(self.handle, 1 if on else 0))
+    def profile(self, on) -> None:
+        """0/False off, 1/True full (markers around every encode and step), 2 cross-attention dispatch events only."""
+        _lib.check(self.lib.txo_profile_enable(self.handle, int(on)))
 
     def profile_read(self, kind: int):
         ms, n = C.c_double(0), C.c_int64(0)
