@@ -100,6 +100,8 @@ def main():
             raise RuntimeError(f"expected {a.max_len} decode steps, got {toks.shape[1]}")
         return all_gather_rows(toks, counts) if world > 1 else toks
 
+    if not a.no_roofline and rank == 0:
+        eng.profile(2); eng.profile(0)          # creates the event pool now, outside the timed region
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < a.settle_seconds:      # local work only: ranks may run different counts
         model.generate(imgs[0], a.max_len)
@@ -114,8 +116,9 @@ def main():
     lat = []
     for i in range(a.steps):
         if i == a.steps - 1 and not a.no_roofline and rank == 0:
-            # the cross-attention dispatches of the LAST timed step carry HIP events (bound to the dispatch, no extra commands
-            # on the stream).  Only one step: event-carrying launches cost 9 % of a step's wall time, which `value` must not pay K times.
+            # every fourth cross-attention dispatch of the LAST timed step carries HIP events (bound to the dispatch, no extra
+            # commands on the stream).  An event-carrying launch costs ~2 us of wall time (9 % of a step with all of them
+            # instrumented), which `value` must not pay K times.
             eng.profile(2)
         s0 = time.perf_counter()
         out = step(i)

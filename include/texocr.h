@@ -118,8 +118,8 @@ int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint
  * the encoder launches recorded with HIP events on the stream the kernels run on, since profiling was last
  * enabled (txo_profile_enable(e, 1) also clears the previous samples); *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,
  * 1 = encoder (whole txo_encode), 2 = whole decode step.
- * on = 1: everything above (adds marker commands around every encode and step -- use in a separate pass); on = 2: only the
- * cross-attention dispatches carry events (bound to the dispatch, no extra commands; safe inside a timed region; samples are
+ * on = 1: everything above (adds marker commands around every encode and step -- use in a separate pass); on = 2: only every
+ * fourth cross-attention dispatch carries events (bound to the dispatch, no extra commands; safe inside a timed region; samples are
  * kept for the first 16 generate() calls after enabling); on = 0: off. */
 int txo_profile_enable(txo_engine* e, int32_t on);
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count);
