@@ -506,3 +506,32 @@ def test_large_ragged_batch_rows_independent():
         tail_t, tail_l = mm.generate(img[66:].cuda(), 12, return_logits=True)      # rows 66..129 as a 64-row batch
         assert torch.equal(big_t[66:], tail_t), dtype
         assert torch.equal(big_l[66:], tail_l), dtype
+
+
+def test_bf16_dma_gemm_bit_identical_to_register_staged(monkeypatch):
+    """The 256x256 LDS-DMA GEMM (gemm_pp.h) and the 128x128 register-staged GEMM (gemm_big.h) accumulate every output element in
+    the same order, so the bf16 engine must give bit-identical encoder features and tokens with either (TXO_GEMM_OLD=1 forces
+    the latter).  Ragged row count (B * 589 is not a multiple of 256) and every epilogue (heads scatter, GLU + residual, GeGLU,
+    bias + residual, cross K/V store) are on the path; repeated to screen for timing-dependent races."""
+    d = Dims(canvas=672)
+    img = torch.from_numpy(synth.synth_images(12, 3, 224, 672, seed=91)).cuda()
+    monkeypatch.setenv("TXO_GEMM_OLD", "1")
+    _, _, m_old = build(d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
+    monkeypatch.delenv("TXO_GEMM_OLD")
+    _, _, m_new = build(d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
+    m_old.eos_token = None; m_new.eos_token = None
+    enc_old = m_old.encoder(img)
+    for _ in range(5):
+        assert torch.equal(m_new.encoder(img), enc_old)
+    t_old, l_old = m_old.generate(img, 24, return_logits=True)
+    t_new, l_new = m_new.generate(img, 24, return_logits=True)
+    assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old)
+    # ViT-Base widths (K = 768 / 3072: 12 and 48 K tiles)
+    d2 = Dims(canvas=672, embed_dim=768, enc_heads=12, enc_layers=2, dec_heads=12, dec_layers=1)
+    monkeypatch.setenv("TXO_GEMM_OLD", "1")
+    _, _, b_old = build(d2, seed=6, dtype="bf16", max_batch=12, max_tokens=589)
+    monkeypatch.delenv("TXO_GEMM_OLD")
+    _, _, b_new = build(d2, seed=6, dtype="bf16", max_batch=12, max_tokens=589)
+    ref = b_old.encoder(img)
+    for _ in range(3):
+        assert torch.equal(b_new.encoder(img), ref)

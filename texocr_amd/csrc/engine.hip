@@ -21,6 +21,7 @@
 #include "dec_gemm.h"
 #include "enc_attn.h"
 #include "gemm_big.h"
+#include "gemm_pp.h"
 #include "rows.h"
 #include "step.h"
 
@@ -126,6 +127,7 @@ struct Engine : EngineBase {
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
+    bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     int step_host_t = -1;             // position of the step being enqueued when the host knows it (see enqueue_step)
     // TXO_STAMPS=<file>: diagnostic -- every decode launch of ONE step records per-block entry / mid / exit times
     unsigned long long* stamp_buf = nullptr; int stamp_slot = -1; static constexpr int STAMP_BLOCKS = 2048, STAMP_KERNELS = 64;
@@ -461,6 +463,16 @@ struct Engine : EngineBase {
         else hipLaunchKernelGGL((ln_rows_generic_kernel<TZ, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, D);
     }
 
+    // C = A * W^T with A plain row-major [M][K]: the 256x256 LDS-DMA kernel (gemm_pp.h) for bf16 shapes it fits, else the
+    // 128x128 register-staged kernel.  TXO_GEMM_OLD=1 forces the latter (tests compare the two bit for bit).
+    template <class Epi>
+    void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi) {
+        if constexpr (sizeof(T) == 2) {
+            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi); return; }
+        }
+        launch_gemm_big<T>(s, LoadPlain<T>{A, K}, W, M, N, K, epi);
+    }
+
     // ---- hybrid embedder: ResNetV2 [2,4,6] on NHWC activations (conv.h) -----------------------------------------
     static void same_pad(int in, int k, int stride, int* out, int* pad_lo) {   // utils.py:97-99,112-123 (TF "SAME")
         *out = (in + stride - 1) / stride;
@@ -537,7 +549,7 @@ struct Engine : EngineBase {
         } else {
             const T* feat = nullptr;
             if (int r = backbone(img, B, H, W, &feat, s)) return r;
-            launch_gemm_big<T>(s, LoadPlain<T>{feat, 1024}, patch_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
+            gemm_plain(s, feat, patch_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
         }
         const size_t hs = (size_t)M * Ie;      // one of q/k/v, head-major [B*heads][N][64]
         for (int l = 0; l < cfg.enc_layers; ++l) {
@@ -545,22 +557,22 @@ struct Engine : EngineBase {
             else launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
             const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);
             if constexpr (sizeof(T) == 4) {
-                launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
+                gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N});
                 hipLaunchKernelGGL((enc_attn_kernel<T>), agrid, dim3(256), 0, s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N,
                                    cfg.enc_heads);
             } else {                                              // perf mode: bf16 q/k/v, bf16 MFMA attention
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
-                launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_attn[l].wqkv, M, 3 * Ie, D,
+                gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N});
                 hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N,
                                    cfg.enc_heads);
             }
-            launch_gemm_big<T>(s, LoadPlain<T>{eao, Ie}, enc_attn[l].wo, M, 2 * D, Ie,
+            gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
                                EpiGluRes{ey, ex, enc_attn[l].bo, D});
             launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
-            launch_gemm_big<T>(s, LoadPlain<T>{ez, D}, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
-            launch_gemm_big<T>(s, LoadPlain<T>{ehid, Fe}, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, ex, enc_mlp[l].b2, D});
+            gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
+            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, ex, enc_mlp[l].b2, D});
         }
         launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M);
         if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }
@@ -581,7 +593,7 @@ struct Engine : EngineBase {
             a_enc = enc_t;
         }
         // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D]
-        launch_gemm_big<T>(s, LoadPlain<T>{a_enc, D}, wckv, M, cfg.dec_layers * 2 * Id, D,
+        gemm_plain(s, a_enc, wckv, M, cfg.dec_layers * 2 * Id, D,
                            EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, N});
         sB = B; sN = N; sImg = B; session = true;
         set_lanes(1, s);

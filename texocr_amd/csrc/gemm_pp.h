@@ -1,0 +1,175 @@
+// bf16 GEMM for the large encoder-side projections:  C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), A and W plain row-major bf16.
+//
+// Same operations and epilogues as gemm_big.h (reference model/attention.py:124-127 q/k/v, :96-99,180 gated out-proj,
+// :15-17 GeGLU FFN-in, :63-67 FFN-out, :125-126 cross K/V), restructured for the MFMA-bound regime (ViT-Base, BASELINE
+// configs[3]) where the 128x128 register-staged kernel reaches ~0.6 PFLOP/s:
+//   * 256 x 256 block tile, 512 threads = 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA 16x16x32 tiles
+//     (128 accumulator registers) -- twice the MFMA work per byte staged and per LDS fragment read;
+//   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).  One wave
+//     instruction writes 1 KiB = 8 rows x 128 B linearly; the XOR piece swizzle that keeps the ds_read_b128 fragment reads
+//     conflict free is applied on the SOURCE side (lane (row, slot) fetches piece slot ^ (row & 7));
+//   * K in 64-element (128-byte) tiles, two LDS buffers of 64 KiB; the DMA of tile t+1 is in flight under the MFMAs of
+//     tile t: counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue);
+//   * one block per CU (128 KiB LDS), two waves per SIMD: while one wave waits for fragments the other issues MFMAs;
+//   * epilogue: each wave stages its own 64 x 64 accumulator quarter through LDS (no block barrier) and hands 8-column
+//     row segments to the same epilogue functors as gemm_big.h.
+// Accumulation order per output element is the same as gemm_big_kernel<bf16> (k ascending in 32-element MFMA chunks),
+// so both kernels produce bit-identical results -- tests compare them.
+// Requires K % 64 == 0 and N % 256 == 0 (every encoder GEMM of the reference configurations); rows are ragged (M is
+// B * tokens): loads clamp to the last row, stores are masked.
+// Bound: MFMA (bf16 dense peak 2.5 PFLOP/s).
+#pragma once
+#include "common.h"
+#include "gemm_big.h"
+
+namespace txo {
+
+constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
+constexpr int PP_TILE_BYTES = PP_BM * 128;            // one operand tile: 256 rows x 128 B
+constexpr int PP_BUF_BYTES = 2 * PP_TILE_BYTES;       // A + W
+constexpr int PP_LDS_BYTES = 2 * PP_BUF_BYTES;        // two buffers = 128 KiB
+
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform) + lane * 16
+__device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)gsrc,
+                                     (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
+}
+
+template <class Epi>
+__global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
+                                                                int K, int tiles_n, int n_tiles, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];     // ONE array: [buf][A|W][row*128]
+
+    // XCD-aware tile order (bijective): blocks that share an XCD walk consecutive tiles of one A row panel
+    int bid = blockIdx.x;
+    {
+        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;              // waves w and w+4 share a SIMD: same columns, other row half
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // ---- DMA source addresses: per operand 4 wave-instructions per K tile; instruction j covers rows j*64 + wave*8 .. +7
+    const int drow = lane >> 3, dslot = lane & 7;
+    const bf16* asrc[4]; const bf16* wsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 64 + wave * 8 + drow;        // row inside the 256-row tile
+        const int piece = dslot ^ (row & 7);             // swizzle on the source side: LDS slot dslot holds this piece
+        asrc[j] = A + (size_t)min(m0 + row, M - 1) * K + piece * 8;
+        wsrc[j] = W + (size_t)(n0 + row) * K + piece * 8;
+    }
+    auto issue_tile = [&](int t, int buf) {
+        unsigned char* base = lds + buf * PP_BUF_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(asrc[j] + t * PP_BK, base + (j * 64 + wave * 8) * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(wsrc[j] + t * PP_BK, base + PP_TILE_BYTES + (j * 64 + wave * 8) * 128);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / PP_BK;
+    issue_tile(0, 0);
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        // tile t+1 goes into the other buffer, whose last readers passed the barrier that ended iteration t-1
+        if (t + 1 < nk) {
+            issue_tile(t + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 8 DMAs of tile t have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                              // ... and every other wave's
+        const unsigned char* la = lds + buf * PP_BUF_BYTES;
+        const unsigned char* lw = la + PP_TILE_BYTES;
+        u32x4 fb[4][2];                                            // the wave's 64 columns x 64 k: read once per tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                              // two 64-row halves of the wave's 128 rows
+            u32x4 fa[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + h * 64 + i * 16 + lr, ks * 4 + lg));
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mma16<bf16>(acc[h * 4 + i][j], fa[i][ks], fb[j][ks]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // everyone is done reading buffer `buf`
+    }
+
+    // ---- epilogue: per wave, four 64-row x 64-col... two halves of 64 rows staged through the wave's own 16 KiB of LDS ----
+    float* stage = reinterpret_cast<float*>(lds + wave * 16384);   // [64][64] f32, 16-byte column groups XOR-swizzled by row
+    auto sidx = [](int row, int col) { return row * 64 + (col ^ (((row >> 2) & 1) << 4)); };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[sidx(i * 16 + lg * 4 + r, j * 16 + lr)] = acc[h * 4 + i][j][r];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private region: no barrier needed
+        const int mbase = m0 + wr * 128 + h * 64, nbase = n0 + wc * 64;
+        if constexpr (Epi::PAIRED) {
+            // 64 columns = two [16 value | 16 gate] groups -> four value groups of 8 per row
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int idx = lane + 64 * q, row = idx >> 2, vg = idx & 3;
+                const int cv = (vg >> 1) * 32 + (vg & 1) * 8, m = mbase + row, nv = nbase + cv, ng = nv + 16;
+                if (m < M) {
+                    float v[8], g[8];
+                    load8(&stage[sidx(row, cv)], v); load8(&stage[sidx(row, cv + 16)], g);
+                    epi(m, (nv >> 5) * 16 + (nv & 15), nv, ng, v, g);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int idx = lane + 64 * q, row = idx >> 3, cg = idx & 7;
+                const int m = mbase + row, n = nbase + cg * 8;
+                if (m < M) {
+                    float v[8];
+                    load8(&stage[sidx(row, cg * 8)], v);
+                    epi(m, n, v);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // reads done before the next half overwrites the region
+    }
+}
+
+// true when the shape fits this kernel; otherwise the caller uses gemm_big_kernel
+inline bool gemm_pp_fits(int M, int N, int K) { return K % PP_BK == 0 && N % PP_BN == 0 && M >= PP_BM; }
+
+template <class Epi>
+inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi) {
+    const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
+    const int n_tiles = tiles_m * tiles_n;
+    static bool attr_set = false;                     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PP_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_pp_kernel<Epi>), dim3(n_tiles), dim3(PP_THREADS), PP_LDS_BYTES, s, A, W, M, N, K, tiles_n, n_tiles, epi);
+}
+
+}  // namespace txo
