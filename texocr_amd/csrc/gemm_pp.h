@@ -8,9 +8,10 @@
 //   * operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write pass).  One wave
 //     instruction writes 1 KiB = 8 rows x 128 B linearly; the XOR piece swizzle that keeps the ds_read_b128 fragment reads
 //     conflict free is applied on the SOURCE side (lane (row, slot) fetches piece slot ^ (row & 7));
-//   * K in 64-element (128-byte) tiles, two LDS buffers of 64 KiB; the DMA of tile t+1 is in flight under the MFMAs of
-//     tile t: counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue);
-//   * one block per CU (128 KiB LDS), two waves per SIMD: while one wave waits for fragments the other issues MFMAs;
+//   * K in 64-element (128-byte) tiles, two LDS buffers of 64 KiB managed as half-tiles; DMA runs 1 - 1.5 tiles ahead of the
+//     MFMAs: counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue);
+//   * one block per CU (128 KiB LDS), two waves per SIMD, and the two wave groups run their phases one barrier apart: while
+//     one wave of a SIMD issues its 16 MFMAs the other reads fragments and issues DMA (main-loop comment below);
 //   * epilogue: each wave stages its own 64 x 64 accumulator quarter through LDS (no block barrier) and hands 8-column
 //     row segments to the same epilogue functors as gemm_big.h.
 // Accumulation order per output element is the same as gemm_big_kernel<bf16> (k ascending in 32-element MFMA chunks),
@@ -54,22 +55,26 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
     const int wr = wave >> 2, wc = wave & 3;              // waves w and w+4 share a SIMD: same columns, other row half
     const int lr = lane & 15, lg = lane >> 4;
 
-    // ---- DMA source addresses: per operand 4 wave-instructions per K tile; instruction j covers rows j*64 + wave*8 .. +7
+    // ---- DMA source addresses.  Operand tiles are moved as half-tiles of 128 rows x 128 B (16 KiB): 2 wave-instructions
+    // per wave, instruction j covers rows j*64 + wave*8 .. +7 of the half.  LDS slot (row, dslot) <- source piece dslot ^ (row & 7).
     const int drow = lane >> 3, dslot = lane & 7;
-    const bf16* asrc[4]; const bf16* wsrc[4];
+    const bf16* asrc[2][2]; const bf16* wsrc[2][2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int row = j * 64 + wave * 8 + drow;        // row inside the 256-row tile
-        const int piece = dslot ^ (row & 7);             // swizzle on the source side: LDS slot dslot holds this piece
-        asrc[j] = A + (size_t)min(m0 + row, M - 1) * K + piece * 8;
-        wsrc[j] = W + (size_t)(n0 + row) * K + piece * 8;
-    }
-    auto issue_tile = [&](int t, int buf) {
-        unsigned char* base = lds + buf * PP_BUF_BYTES;
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(asrc[j] + t * PP_BK, base + (j * 64 + wave * 8) * 128);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(wsrc[j] + t * PP_BK, base + PP_TILE_BYTES + (j * 64 + wave * 8) * 128);
+        for (int j = 0; j < 2; ++j) {
+            const int row = x * 128 + j * 64 + wave * 8 + drow;      // row inside the 256-row tile
+            const int piece = dslot ^ (row & 7);
+            asrc[x][j] = A + (size_t)min(m0 + row, M - 1) * K + piece * 8;
+            wsrc[x][j] = W + (size_t)(n0 + row) * K + piece * 8;
+        }
+    // half-tile x of operand `op` (0 = A, 1 = W) of K tile t -> buffer buf
+    auto issue_half = [&](int op, int x, int t, int buf) {
+        unsigned char* base = lds + buf * PP_BUF_BYTES + op * PP_TILE_BYTES + x * (PP_TILE_BYTES / 2) + wave * 8 * 128;
+        const bf16* s0 = op ? wsrc[x][0] : asrc[x][0];
+        const bf16* s1 = op ? wsrc[x][1] : asrc[x][1];
+        dma16(s0 + t * PP_BK, base);
+        dma16(s1 + t * PP_BK, base + 64 * 128);
     };
 
     f32x4 acc[8][4];
@@ -78,42 +83,80 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- main loop: four phases per K tile, one accumulator quadrant (64 rows x 32 columns x 64 k = 16 MFMAs) each.
+    // A phase = memory part {fragment ds_reads, one half-tile of DMA, waits} | barrier | 16 MFMAs | barrier.  The two wave
+    // groups (wr = 0 / 1; waves w and w+4 share a SIMD) run one barrier apart, so that on every SIMD one wave issues MFMAs
+    // while the other fetches.
+    //   reads per phase   P1: W[c0] + A[h0]   P2: W[c1]   P3: A[h1]   P4: none (W[c0] stays in registers)
+    //   DMA per phase     P1: A0(t+1)  P2: A1(t+1)  P3: W0(t+2)  P4: W1(t+2)   -- A one tile ahead, W a tile and a half
+    // Slot reuse (WAR): every memory part ends with lgkmcnt(0) BEFORE its barrier, so a slot's last reads (A: P3, W: P2) are
+    // complete two barriers before the DMA that refills it is issued.  Arrival (RAW): the counted vmcnt at P4 retires
+    // everything but the two W halves just issued; both groups have passed that wait before either reads tile t+1.
     const int nk = K / PP_BK;
-    issue_tile(0, 0);
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        // tile t+1 goes into the other buffer, whose last readers passed the barrier that ended iteration t-1
-        if (t + 1 < nk) {
-            issue_tile(t + 1, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // this wave's 8 DMAs of tile t have landed
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();                              // ... and every other wave's
-        const unsigned char* la = lds + buf * PP_BUF_BYTES;
-        const unsigned char* lw = la + PP_TILE_BYTES;
-        u32x4 fb[4][2];                                            // the wave's 64 columns x 64 k: read once per tile
+    issue_half(1, 0, 0, 0); issue_half(1, 1, 0, 0); issue_half(0, 0, 0, 0); issue_half(0, 1, 0, 0);
+    issue_half(1, 0, 1, 1); issue_half(1, 1, 1, 1);                       // nk >= 2 (gemm_pp_fits)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();                            // stagger the second group by one barrier
+
+    u32x4 fa[4][2], fb0[2][2], fb1[2][2];
+    auto mfma_quadrant = [&](int h, const u32x4 (&fb)[2][2], int c) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                              // two 64-row halves of the wave's 128 rows
-            u32x4 fa[4][2];
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + h * 64 + i * 16 + lr, ks * 4 + lg));
+                for (int j = 0; j < 2; ++j) mma16<bf16>(acc[h * 4 + i][c * 2 + j], fa[i][ks], fb[j][ks]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    for (int t = 0; t < nk; ++t) {
+        const int buf = t & 1;
+        const unsigned char* la = lds + buf * PP_BUF_BYTES;
+        const unsigned char* lw = la + PP_TILE_BYTES;
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        // ---- P1: (h0, c0)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mma16<bf16>(acc[h * 4 + i][j], fa[i][ks], fb[j][ks]);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + i * 16 + lr, ks * 4 + lg));
+        if (more1) issue_half(0, 0, t + 1, buf ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                              // everyone is done reading buffer `buf`
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(0, fb0, 0);
+        __builtin_amdgcn_s_barrier();
+        // ---- P2: (h0, c1)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = ld16(lw + swz128(wc * 64 + 32 + j * 16 + lr, ks * 4 + lg));
+        if (more1) issue_half(0, 1, t + 1, buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(0, fb1, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- P3: (h1, c1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + 64 + i * 16 + lr, ks * 4 + lg));
+        if (more2) issue_half(1, 0, t + 2, buf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(1, fb1, 1);
+        __builtin_amdgcn_s_barrier();
+        // ---- P4: (h1, c0)
+        if (more2) { issue_half(1, 1, t + 2, buf); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_quadrant(1, fb0, 0);
+        __builtin_amdgcn_s_barrier();
     }
+    if (wr == 0) __builtin_amdgcn_s_barrier();                            // the first group catches up: all LDS reads are done
 
     // ---- epilogue: per wave, four 64-row x 64-col... two halves of 64 rows staged through the wave's own 16 KiB of LDS ----
     float* stage = reinterpret_cast<float*>(lds + wave * 16384);   // [64][64] f32, 16-byte column groups XOR-swizzled by row
@@ -157,7 +200,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 }
 
 // true when the shape fits this kernel; otherwise the caller uses gemm_big_kernel
-inline bool gemm_pp_fits(int M, int N, int K) { return K % PP_BK == 0 && N % PP_BN == 0 && M >= PP_BM; }
+inline bool gemm_pp_fits(int M, int N, int K) { return K % PP_BK == 0 && K >= 2 * PP_BK && N % PP_BN == 0 && M >= PP_BM; }
 
 template <class Epi>
 inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi) {
