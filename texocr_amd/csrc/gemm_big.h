@@ -74,6 +74,20 @@ template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
             for (int e = 0; e < 8; ++e) v[e] += b[e]; }
         store8<T>(out + (size_t)m * ldo + n, v);
     }
+    // split form (gemm_pp.h): column operands once per lane, row operands batched ahead of the arithmetic, masked store
+    static constexpr bool HAS_ROW = false;
+    __device__ inline void cols(int n, float (&cb)[16]) const {
+        if (bias) load8(bias + n, reinterpret_cast<float (&)[8]>(cb));
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cb[e] = 0.f; }
+    }
+    __device__ inline void rowop(int, int, float (&)[8]) const {}
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += cb[e];
+        if (valid) store8<T>(out + (size_t)m * ldo + n, v);
+    }
 };
 template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
     T* base; size_t which_stride; int inner, heads, ntok;
@@ -82,6 +96,12 @@ template <typename T> struct EpiHeads {           // scatter n = (which, head, d
         const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
         const int b = m / ntok, t = m - b * ntok;
         store8<T>(base + which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d, v);
+    }
+    static constexpr bool HAS_ROW = false;
+    __device__ inline void cols(int, float (&)[16]) const {}
+    __device__ inline void rowop(int, int, float (&)[8]) const {}
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&)[16], const float (&)[8], bool valid) const {
+        if (valid) (*this)(m, n, v);
     }
 };
 struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoid(g+bg) + resid[m][j..]   (fp32 stream)
@@ -94,6 +114,16 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoidf(g[e] + bg[e]) + r[e];
         store8<float>(y + (size_t)m * D + j, v);
     }
+    static constexpr bool HAS_ROW = true;
+    __device__ inline void cols(int nv, int ng, float (&cb)[16]) const {
+        load8(bias + nv, reinterpret_cast<float (&)[8]>(cb)); load8(bias + ng, reinterpret_cast<float (&)[8]>(cb[8]));
+    }
+    __device__ inline void rowop(int m, int j, float (&r)[8]) const { load8(resid + (size_t)m * D + j, r); }
+    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * sigmoidf(g[e] + cb[8 + e]) + r[e];
+        if (valid) store8<float>(y + (size_t)m * D + j, v);
+    }
 };
 template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
     T* h; const float* bias; int F;
@@ -105,6 +135,16 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_erf(g[e] + bg[e]);
         store8<T>(h + (size_t)m * F + j, v);
     }
+    static constexpr bool HAS_ROW = false;
+    __device__ inline void cols(int nv, int ng, float (&cb)[16]) const {
+        load8(bias + nv, reinterpret_cast<float (&)[8]>(cb)); load8(bias + ng, reinterpret_cast<float (&)[8]>(cb[8]));
+    }
+    __device__ inline void rowop(int, int, float (&)[8]) const {}
+    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * gelu_erf(g[e] + cb[8 + e]);
+        if (valid) store8<T>(h + (size_t)m * F + j, v);
+    }
 };
 struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
     float* y; const float* resid; const float* bias; int D;
@@ -115,6 +155,14 @@ struct EpiBiasRes {                               // y[m][n..] = acc + bias + re
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += b[e] + r[e];
         store8<float>(y + (size_t)m * D + n, v);
+    }
+    static constexpr bool HAS_ROW = true;
+    __device__ inline void cols(int n, float (&cb)[16]) const { load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); }
+    __device__ inline void rowop(int m, int n, float (&r)[8]) const { load8(resid + (size_t)m * D + n, r); }
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += cb[e] + r[e];
+        if (valid) store8<float>(y + (size_t)m * D + n, v);
     }
 };
 struct EpiPatch {                                 // x[b][1+p][n..] = acc + bias + pos[1 + pr*G + pc][n..]

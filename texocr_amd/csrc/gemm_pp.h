@@ -158,9 +158,25 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();                            // the first group catches up: all LDS reads are done
 
-    // ---- epilogue: per wave, four 64-row x 64-col... two halves of 64 rows staged through the wave's own 16 KiB of LDS ----
-    float* stage = reinterpret_cast<float*>(lds + wave * 16384);   // [64][64] f32, 16-byte column groups XOR-swizzled by row
+    // ---- epilogue: per wave, two 64-row halves of its 128 x 64 accumulator tile staged through the wave's own 16 KiB of
+    // LDS (no block barrier).  A lane keeps one column group for all its items, so the column operands (bias) are loaded
+    // once; the row operands (residual / position rows) of four items are requested together ahead of the arithmetic --
+    // one functor call per item would wait for its own loads sixteen times in a row.
+    float* stage = reinterpret_cast<float*>(lds + wave * 16384);   // [64][64] f32, 16-column groups XOR-swizzled by row
     auto sidx = [](int row, int col) { return row * 64 + (col ^ (((row >> 2) & 1) << 4)); };
+    const int nbase = n0 + wc * 64;
+    float cb[16];
+    int cv = 0, nv = 0;                                            // paired: value columns of this lane; plain: its 8 columns
+    if constexpr (Epi::PAIRED) {
+        const int vg = lane & 3;
+        cv = (vg >> 1) * 32 + (vg & 1) * 8; nv = nbase + cv;
+        epi.cols(nv, nv + 16, cb);
+    } else {
+        cv = (lane & 7) * 8; nv = nbase + cv;
+        epi.cols(nv, cb);
+    }
+    const int jout = Epi::PAIRED ? (nv >> 5) * 16 + (nv & 15) : nv;
+    constexpr int ITEMS = Epi::PAIRED ? 4 : 8, RSTEP = Epi::PAIRED ? 16 : 8, RSHIFT = Epi::PAIRED ? 2 : 3;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -170,28 +186,25 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 #pragma unroll
                 for (int r = 0; r < 4; ++r) stage[sidx(i * 16 + lg * 4 + r, j * 16 + lr)] = acc[h * 4 + i][j][r];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private region: no barrier needed
-        const int mbase = m0 + wr * 128 + h * 64, nbase = n0 + wc * 64;
-        if constexpr (Epi::PAIRED) {
-            // 64 columns = two [16 value | 16 gate] groups -> four value groups of 8 per row
+        const int mbase = m0 + wr * 128 + h * 64;
+#pragma unroll
+        for (int q0 = 0; q0 < ITEMS; q0 += 4) {
+            float rr[4][8];
+            if constexpr (Epi::HAS_ROW) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) epi.rowop(min(mbase + (lane >> RSHIFT) + RSTEP * (q0 + q), M - 1), jout, rr[q]);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int idx = lane + 64 * q, row = idx >> 2, vg = idx & 3;
-                const int cv = (vg >> 1) * 32 + (vg & 1) * 8, m = mbase + row, nv = nbase + cv, ng = nv + 16;
-                if (m < M) {
-                    float v[8], g[8];
-                    load8(&stage[sidx(row, cv)], v); load8(&stage[sidx(row, cv + 16)], g);
-                    epi(m, (nv >> 5) * 16 + (nv & 15), nv, ng, v, g);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int idx = lane + 64 * q, row = idx >> 3, cg = idx & 7;
-                const int m = mbase + row, n = nbase + cg * 8;
-                if (m < M) {
-                    float v[8];
-                    load8(&stage[sidx(row, cg * 8)], v);
-                    epi(m, n, v);
+                const int row = (lane >> RSHIFT) + RSTEP * (q0 + q), m = mbase + row;
+                float v[8];
+                load8(&stage[sidx(row, cv)], v);
+                if constexpr (Epi::PAIRED) {
+                    float g[8];
+                    load8(&stage[sidx(row, cv + 16)], g);
+                    epi.fin(min(m, M - 1), jout, v, g, cb, rr[q], m < M);
+                } else {
+                    epi.fin(min(m, M - 1), jout, v, cb, rr[q], m < M);
                 }
             }
         }
