@@ -12,8 +12,10 @@
 //     MFMAs: counted s_waitcnt vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue);
 //   * one block per CU (128 KiB LDS), two waves per SIMD, and the two wave groups run their phases one barrier apart: while
 //     one wave of a SIMD issues its 16 MFMAs the other reads fragments and issues DMA (main-loop comment below);
-//   * epilogue: each wave stages its own 64 x 64 accumulator quarter through LDS (no block barrier) and hands 8-column
-//     row segments to the same epilogue functors as gemm_big.h.
+//   * persistent blocks (one per CU): the K tiles of a block's successive output tiles form one DMA stream, so the next
+//     tile's operands are already landing while the current tile is written out;
+//   * epilogue: each wave stages its accumulators through its own 4 KiB of LDS sixteen rows at a time (no block barrier)
+//     and hands 8-column row segments to the same epilogue functors as gemm_big.h.
 // Accumulation order per output element is the same as gemm_big_kernel<bf16> (k ascending in 32-element MFMA chunks),
 // so both kernels produce bit-identical results -- tests compare them.
 // Requires K % 64 == 0 and N % 256 == 0 (every encoder GEMM of the reference configurations); rows are ragged (M is
@@ -29,6 +31,8 @@ constexpr int PP_BM = 256, PP_BN = 256, PP_BK = 64, PP_THREADS = 512;
 constexpr int PP_TILE_BYTES = PP_BM * 128;            // one operand tile: 256 rows x 128 B
 constexpr int PP_BUF_BYTES = 2 * PP_TILE_BYTES;       // A + W
 constexpr int PP_LDS_BYTES = 2 * PP_BUF_BYTES;        // two buffers = 128 KiB
+constexpr int PP_STAGE_BYTES = 8 * 4096;              // epilogue staging, 4 KiB per wave
+constexpr int PP_SMEM_BYTES = PP_LDS_BYTES + PP_STAGE_BYTES;   // 160 KiB: the whole LDS of a CU
 
 // LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform) + lane * 16
 __device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
@@ -38,43 +42,66 @@ __device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
 
 template <class Epi>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                                int K, int tiles_n, int n_tiles, Epi epi) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];     // ONE array: [buf][A|W][row*128]
-
-    // XCD-aware tile order (bijective): blocks that share an XCD walk consecutive tiles of one A row panel
-    int bid = blockIdx.x;
-    {
-        const int q = n_tiles >> 3, r = n_tiles & 7, xcd = bid & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * PP_BM, n0 = tile_n * PP_BN;
+                                                                int K, int tiles_n, int n_tiles, int ct, Epi epi) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];     // ONE array: [buf][A|W][row*128] + epilogue staging
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;              // waves w and w+4 share a SIMD: same columns, other row half
     const int lr = lane & 15, lg = lane >> 4;
 
-    // ---- DMA source addresses.  Operand tiles are moved as half-tiles of 128 rows x 128 B (16 KiB): 2 wave-instructions
+    // ---- persistent blocks.  Tile order: the output is cut into bands of `ct` column tiles; inside a band tiles run
+    // row-major, and 32 consecutive tiles (one per CU of an XCD: blocks b, b+8, ... share an XCD) form the working set of one
+    // XCD at a time: `ct` column tiles of W stay in that XCD's 4 MiB L2 for the whole band while 32/ct row panels of A
+    // stream through.  With the plain row-panel order an XCD needs ALL of W every round (9.4 MB for the ViT-Base FFN-in:
+    // it comes from the Infinity Cache at ~35 GB/s per CU, which is what bounded the main loop at half the MFMA rate).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, chunks = gridDim.x >> 3;      // gridDim is a multiple of 8
+    auto tile_seq = [&](int seq) { return (seq * 8 + xcd) * chunks + slot; };            // position in the banded order
+    int n_my = 0;
+    while (tile_seq(n_my) < n_tiles) ++n_my;
+    if (n_my == 0) return;
+    const int tiles_m = n_tiles / tiles_n, band_tiles = tiles_m * ct;
+    auto tile_origin = [&](int seq, int& m0, int& n0) {
+        const int L = tile_seq(seq);
+        const int band = L / band_tiles, k = L - band * band_tiles;
+        const int cols = min(ct, tiles_n - band * ct);                                   // the last band may be narrower
+        const int row = k / cols, col = k - row * cols;
+        m0 = row * PP_BM; n0 = (band * ct + col) * PP_BN;
+    };
+
+    // ---- DMA source offsets (elements).  Operand tiles move as half-tiles of 128 rows x 128 B (16 KiB): 2 wave-instructions
     // per wave, instruction j covers rows j*64 + wave*8 .. +7 of the half.  LDS slot (row, dslot) <- source piece dslot ^ (row & 7).
+    // The A stream and the W stream run ahead of the MFMAs by different distances, so each keeps the offsets of the tile
+    // it is currently fetching for.
     const int drow = lane >> 3, dslot = lane & 7;
-    const bf16* asrc[2][2]; const bf16* wsrc[2][2];
+    int aoff[2][2], woff[2][2];
+    auto set_aoff = [&](int seq) {
+        int m0, n0; tile_origin(seq, m0, n0);
 #pragma unroll
-    for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int row = x * 128 + j * 64 + wave * 8 + drow;      // row inside the 256-row tile
-            const int piece = dslot ^ (row & 7);
-            asrc[x][j] = A + (size_t)min(m0 + row, M - 1) * K + piece * 8;
-            wsrc[x][j] = W + (size_t)(n0 + row) * K + piece * 8;
-        }
-    // half-tile x of operand `op` (0 = A, 1 = W) of K tile t -> buffer buf
-    auto issue_half = [&](int op, int x, int t, int buf) {
+            for (int j = 0; j < 2; ++j) {
+                const int row = x * 128 + j * 64 + wave * 8 + drow;
+                aoff[x][j] = min(m0 + row, M - 1) * K + (dslot ^ (row & 7)) * 8;
+            }
+    };
+    auto set_woff = [&](int seq) {
+        int m0, n0; tile_origin(seq, m0, n0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = x * 128 + j * 64 + wave * 8 + drow;
+                woff[x][j] = (n0 + row) * K + (dslot ^ (row & 7)) * 8;
+            }
+    };
+    // half-tile x of operand `op` (0 = A, 1 = W), K tile kt of the stream's current tile -> buffer buf
+    auto issue_half = [&](int op, int x, int kt, int buf) {
         unsigned char* base = lds + buf * PP_BUF_BYTES + op * PP_TILE_BYTES + x * (PP_TILE_BYTES / 2) + wave * 8 * 128;
-        const bf16* s0 = op ? wsrc[x][0] : asrc[x][0];
-        const bf16* s1 = op ? wsrc[x][1] : asrc[x][1];
-        dma16(s0 + t * PP_BK, base);
-        dma16(s1 + t * PP_BK, base + 64 * 128);
+        const bf16* src = op ? W : A;
+        const int o0 = op ? woff[x][0] : aoff[x][0], o1 = op ? woff[x][1] : aoff[x][1];
+        dma16(src + o0 + kt * PP_BK, base);
+        dma16(src + o1 + kt * PP_BK, base + 64 * 128);
     };
 
     f32x4 acc[8][4];
@@ -83,16 +110,19 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- main loop: four phases per K tile, one accumulator quadrant (64 rows x 32 columns x 64 k = 16 MFMAs) each.
-    // A phase = memory part {fragment ds_reads, one half-tile of DMA, waits} | barrier | 16 MFMAs | barrier.  The two wave
-    // groups (wr = 0 / 1; waves w and w+4 share a SIMD) run one barrier apart, so that on every SIMD one wave issues MFMAs
-    // while the other fetches.
+    // ---- main loop: the K tiles of all this block's output tiles form ONE stream g = 0 .. n_my*nk-1 (the DMA of the next
+    // output tile's first K tiles is in flight while the current tile is finished and written out).  Four phases per K
+    // tile, one accumulator quadrant (64 rows x 32 columns x 64 k = 16 MFMAs) each.  A phase = memory part {fragment
+    // ds_reads, one half-tile of DMA, waits} | barrier | 16 MFMAs | barrier.  The two wave groups (wr = 0 / 1; waves w and
+    // w+4 share a SIMD) run one barrier apart, so that on every SIMD one wave issues MFMAs while the other fetches.
     //   reads per phase   P1: W[c0] + A[h0]   P2: W[c1]   P3: A[h1]   P4: none (W[c0] stays in registers)
-    //   DMA per phase     P1: A0(t+1)  P2: A1(t+1)  P3: W0(t+2)  P4: W1(t+2)   -- A one tile ahead, W a tile and a half
-    // Slot reuse (WAR): every memory part ends with lgkmcnt(0) BEFORE its barrier, so a slot's last reads (A: P3, W: P2) are
-    // complete two barriers before the DMA that refills it is issued.  Arrival (RAW): the counted vmcnt at P4 retires
-    // everything but the two W halves just issued; both groups have passed that wait before either reads tile t+1.
-    const int nk = K / PP_BK;
+    //   DMA per phase     P1: A0(g+1)  P2: A1(g+1)  P3: W0(g+2)  P4: W1(g+2)   -- A one tile ahead, W a tile and a half
+    // Slot reuse (WAR): a W slot's last reads are at P2 and complete (lgkmcnt(0)) before that phase's barrier, two barriers
+    // before the DMA that refills it; an A slot is refilled a whole tile after its last read.  Arrival (RAW): the counted
+    // vmcnt at P4 retires everything but the two W halves just issued; both groups have passed that wait before either
+    // reads tile g+1.
+    const int nk = K / PP_BK, total = n_my * nk;
+    set_aoff(0); set_woff(0);
     issue_half(1, 0, 0, 0); issue_half(1, 1, 0, 0); issue_half(0, 0, 0, 0); issue_half(0, 1, 0, 0);
     issue_half(1, 0, 1, 1); issue_half(1, 1, 1, 1);                       // nk >= 2 (gemm_pp_fits)
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -110,122 +140,152 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
                 for (int j = 0; j < 2; ++j) mma16<bf16>(acc[h * 4 + i][c * 2 + j], fa[i][ks], fb[j][ks]);
         __builtin_amdgcn_s_setprio(0);
     };
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        const unsigned char* la = lds + buf * PP_BUF_BYTES;
-        const unsigned char* lw = la + PP_TILE_BYTES;
-        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
-        // ---- P1: (h0, c0)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + i * 16 + lr, ks * 4 + lg));
-        if (more1) issue_half(0, 0, t + 1, buf ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mfma_quadrant(0, fb0, 0);
-        __builtin_amdgcn_s_barrier();
-        // ---- P2: (h0, c1)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = ld16(lw + swz128(wc * 64 + 32 + j * 16 + lr, ks * 4 + lg));
-        if (more1) issue_half(0, 1, t + 1, buf ^ 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mfma_quadrant(0, fb1, 1);
-        __builtin_amdgcn_s_barrier();
-        // ---- P3: (h1, c1)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + 64 + i * 16 + lr, ks * 4 + lg));
-        if (more2) issue_half(1, 0, t + 2, buf);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mfma_quadrant(1, fb1, 1);
-        __builtin_amdgcn_s_barrier();
-        // ---- P4: (h1, c0)
-        if (more2) { issue_half(1, 1, t + 2, buf); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        mfma_quadrant(1, fb0, 0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (wr == 0) __builtin_amdgcn_s_barrier();                            // the first group catches up: all LDS reads are done
 
-    // ---- epilogue: per wave, two 64-row halves of its 128 x 64 accumulator tile staged through the wave's own 16 KiB of
-    // LDS (no block barrier).  A lane keeps one column group for all its items, so the column operands (bias) are loaded
-    // once; the row operands (residual / position rows) of four items are requested together ahead of the arithmetic --
-    // one functor call per item would wait for its own loads sixteen times in a row.
-    float* stage = reinterpret_cast<float*>(lds + wave * 16384);   // [64][64] f32, 16-column groups XOR-swizzled by row
+    // epilogue staging: 4 KiB per wave behind the two buffers (the buffers hold the next tile's operands by then)
+    float* stage = reinterpret_cast<float*>(lds + PP_LDS_BYTES + wave * 4096);   // [16][64] f32, 16-column groups XOR-swizzled
     auto sidx = [](int row, int col) { return row * 64 + (col ^ (((row >> 2) & 1) << 4)); };
-    const int nbase = n0 + wc * 64;
-    float cb[16];
-    int cv = 0, nv = 0;                                            // paired: value columns of this lane; plain: its 8 columns
-    if constexpr (Epi::PAIRED) {
-        const int vg = lane & 3;
-        cv = (vg >> 1) * 32 + (vg & 1) * 8; nv = nbase + cv;
-        epi.cols(nv, nv + 16, cb);
-    } else {
-        cv = (lane & 7) * 8; nv = nbase + cv;
-        epi.cols(nv, cb);
-    }
-    const int jout = Epi::PAIRED ? (nv >> 5) * 16 + (nv & 15) : nv;
-    constexpr int ITEMS = Epi::PAIRED ? 4 : 8, RSTEP = Epi::PAIRED ? 16 : 8, RSHIFT = Epi::PAIRED ? 2 : 3;
+
+    int g = 0;
+    for (int seq = 0; seq < n_my; ++seq) {
+        for (int kt = 0; kt < nk; ++kt, ++g) {
+            const int buf = g & 1;
+            const unsigned char* la = lds + buf * PP_BUF_BYTES;
+            const unsigned char* lw = la + PP_TILE_BYTES;
+            const bool more1 = g + 1 < total, more2 = g + 2 < total;
+            const int kta = (kt + 1 == nk) ? 0 : kt + 1;                  // K tile the A stream fetches now
+            const int ktw = (kt + 2 >= nk) ? kt + 2 - nk : kt + 2;        // ... and the W stream
+            // ---- P1: (h0, c0)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) stage[sidx(i * 16 + lg * 4 + r, j * 16 + lr)] = acc[h * 4 + i][j][r];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // wave-private region: no barrier needed
-        const int mbase = m0 + wr * 128 + h * 64;
-#pragma unroll
-        for (int q0 = 0; q0 < ITEMS; q0 += 4) {
-            float rr[4][8];
-            if constexpr (Epi::HAS_ROW) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) epi.rowop(min(mbase + (lane >> RSHIFT) + RSTEP * (q0 + q), M - 1), jout, rr[q]);
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + i * 16 + lr, ks * 4 + lg));
+            if (more1) {
+                if (kt + 1 == nk) set_aoff(seq + 1);                      // the A stream moves on to the next output tile
+                issue_half(0, 0, kta, buf ^ 1);
             }
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, fb0, 0);
+            __builtin_amdgcn_s_barrier();
+            // ---- P2: (h0, c1)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int row = (lane >> RSHIFT) + RSTEP * (q0 + q), m = mbase + row;
-                float v[8];
-                load8(&stage[sidx(row, cv)], v);
-                if constexpr (Epi::PAIRED) {
-                    float g[8];
-                    load8(&stage[sidx(row, cv + 16)], g);
-                    epi.fin(min(m, M - 1), jout, v, g, cb, rr[q], m < M);
-                } else {
-                    epi.fin(min(m, M - 1), jout, v, cb, rr[q], m < M);
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = ld16(lw + swz128(wc * 64 + 32 + j * 16 + lr, ks * 4 + lg));
+            if (more1) issue_half(0, 1, kta, buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(0, fb1, 1);
+            __builtin_amdgcn_s_barrier();
+            // ---- P3: (h1, c1)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) fa[i][ks] = ld16(la + swz128(wr * 128 + 64 + i * 16 + lr, ks * 4 + lg));
+            if (more2) {
+                if (kt + 2 == nk) set_woff(seq + 1);                      // the W stream moves on to the next output tile
+                issue_half(1, 0, ktw, buf);
+            }
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(1, fb1, 1);
+            __builtin_amdgcn_s_barrier();
+            // ---- P4: (h1, c0)
+            if (more2) { issue_half(1, 1, ktw, buf); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            mfma_quadrant(1, fb0, 0);
+            __builtin_amdgcn_s_barrier();
+        }
+
+        // ---- epilogue of output tile seq: the wave's 128 x 64 accumulator tile goes through its own 4 KiB of LDS sixteen
+        // rows at a time.  The two wave groups run it side by side (the first group waits one barrier for the second and
+        // they re-stagger afterwards): coupled through the phase barriers, one group's epilogue would otherwise stall the
+        // other group's MFMAs and the two epilogues would run back to back.  A lane keeps one column group for all its
+        // items, so the column operands (bias) are loaded once per tile.
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        {
+            int m0, n0; tile_origin(seq, m0, n0);
+            const int nbase = n0 + wc * 64;
+            float cb[16];
+            int cv, nv;                                                   // paired: value columns of this lane; plain: its 8 columns
+            if constexpr (Epi::PAIRED) {
+                const int vg = lane & 3;
+                cv = (vg >> 1) * 32 + (vg & 1) * 8; nv = nbase + cv;
+                epi.cols(nv, nv + 16, cb);
+            } else {
+                cv = (lane & 7) * 8; nv = nbase + cv;
+                epi.cols(nv, cb);
+            }
+            const int jout = Epi::PAIRED ? (nv >> 5) * 16 + (nv & 15) : nv;
+            constexpr int ITEMS = Epi::PAIRED ? 1 : 2, RSTEP = Epi::PAIRED ? 16 : 8, RSHIFT = Epi::PAIRED ? 2 : 3;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {                                 // row tile i of the wave: 16 rows x 64 columns
+                const int mbase = m0 + wr * 128 + i * 16;
+                float rr[ITEMS][8];
+                if constexpr (Epi::HAS_ROW) {
+#pragma unroll
+                    for (int q = 0; q < ITEMS; ++q) epi.rowop(min(mbase + (lane >> RSHIFT) + RSTEP * q, M - 1), jout, rr[q]);
                 }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) stage[sidx(lg * 4 + r, j * 16 + lr)] = acc[i][j][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // wave-private region: no barrier needed
+#pragma unroll
+                for (int q = 0; q < ITEMS; ++q) {
+                    const int row = (lane >> RSHIFT) + RSTEP * q, m = mbase + row;
+                    float v[8];
+                    load8(&stage[sidx(row, cv)], v);
+                    if constexpr (Epi::PAIRED) {
+                        float gt[8];
+                        load8(&stage[sidx(row, cv + 16)], gt);
+                        epi.fin(min(m, M - 1), jout, v, gt, cb, rr[q], m < M);
+                    } else {
+                        epi.fin(min(m, M - 1), jout, v, cb, rr[q], m < M);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads done before the next row tile overwrites the region
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // reads done before the next half overwrites the region
+        if (wr == 1 && seq + 1 < n_my) __builtin_amdgcn_s_barrier();      // stagger again for the next tile
     }
 }
 
 // true when the shape fits this kernel; otherwise the caller uses gemm_big_kernel
-inline bool gemm_pp_fits(int M, int N, int K) { return K % PP_BK == 0 && K >= 2 * PP_BK && N % PP_BN == 0 && M >= PP_BM; }
+inline bool gemm_pp_fits(int M, int N, int K) {
+    return K % PP_BK == 0 && K >= 2 * PP_BK && N % PP_BN == 0 && M >= PP_BM && (long long)M * K < (1ll << 31) && (long long)N * K < (1ll << 31);
+}
 
 template <class Epi>
 inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi) {
     const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
     const int n_tiles = tiles_m * tiles_n;
+    static int cus = 0;                               // persistent grid: one block per CU (160 KiB of LDS each)
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
     static bool attr_set = false;                     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  PP_LDS_BYTES);
+                                  PP_SMEM_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<Epi>), dim3(n_tiles), dim3(PP_THREADS), PP_LDS_BYTES, s, A, W, M, N, K, tiles_n, n_tiles, epi);
+    // band width: all column tiles when W is small enough to stay in an XCD's L2 anyway (or K is long: A panels are then
+    // the larger operand and must not be re-streamed per band), else as many column tiles as ~1.6 MB of W
+    const long long w_bytes = (long long)N * K * 2, coltile_bytes = (long long)PP_BN * K * 2;
+    int ct = tiles_n;
+    if (w_bytes > (5ll << 19) && K < 2048) ct = (int)std::max<long long>(1, std::min<long long>(tiles_n, (13ll << 17) / coltile_bytes));
+    if (const char* e = getenv("TXO_PP_CT")) ct = std::max(1, std::min(tiles_n, atoi(e)));
+    // narrower last band: when tiles_n % ct != 0 the row-major walk of the last band uses its own width (tile_origin)
+    const int grid = ((std::min(n_tiles, cus) + 7) / 8) * 8;
+    hipLaunchKernelGGL((gemm_pp_kernel<Epi>), dim3(grid), dim3(PP_THREADS), PP_SMEM_BYTES, s, A, W, M, N, K, tiles_n, n_tiles, ct, epi);
 }
 
 }  // namespace txo
