@@ -40,6 +40,13 @@ __device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
                                      (__attribute__((address_space(3))) void*)(uint32_t)(uintptr_t)lds_base, 16, 0, 0);
 }
 
+#ifdef PP_STAMPS
+__device__ unsigned long long g_pp_dbg[4096];      // scratch/pp_bench.hip: block 0, waves 0 and 4: {loop start, loop end, epilogue end} per tile
+#define PP_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && seq < 64) g_pp_dbg[(seq * 2 + wr) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PP_STAMP(slot) do {} while (0)
+#endif
+
 template <class Epi>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
                                                                 int K, int tiles_n, int n_tiles, int ct, Epi epi) {
@@ -111,16 +118,16 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- main loop: the K tiles of all this block's output tiles form ONE stream g = 0 .. n_my*nk-1 (the DMA of the next
-    // output tile's first K tiles is in flight while the current tile is finished and written out).  Four phases per K
-    // tile, one accumulator quadrant (64 rows x 32 columns x 64 k = 16 MFMAs) each.  A phase = memory part {fragment
-    // ds_reads, one half-tile of DMA, waits} | barrier | 16 MFMAs | barrier.  The two wave groups (wr = 0 / 1; waves w and
+    // output tile's first K tiles is in flight while the current tile is finished and written out).  Two phases per K
+    // tile, half of the wave's accumulators (64 rows x 64 columns x 64 k = 32 MFMAs) each.  A phase = memory part {fragment
+    // ds_reads, two half-tiles of DMA, waits} | barrier | 32 MFMAs | barrier.  The two wave groups (wr = 0 / 1; waves w and
     // w+4 share a SIMD) run one barrier apart, so that on every SIMD one wave issues MFMAs while the other fetches.
-    //   reads per phase   P1: W[c0] + A[h0]   P2: W[c1]   P3: A[h1]   P4: none (W[c0] stays in registers)
-    //   DMA per phase     P1: A0(g+1)  P2: A1(g+1)  P3: W0(g+2)  P4: W1(g+2)   -- A one tile ahead, W a tile and a half
-    // Slot reuse (WAR): a W slot's last reads are at P2 and complete (lgkmcnt(0)) before that phase's barrier, two barriers
-    // before the DMA that refills it; an A slot is refilled a whole tile after its last read.  Arrival (RAW): the counted
-    // vmcnt at P4 retires everything but the two W halves just issued; both groups have passed that wait before either
-    // reads tile g+1.
+    //   reads per phase   a: W[c0], W[c1], A[h0]      b: A[h1]
+    //   DMA per phase     a: A0(g+1), A1(g+1)         b: W0(g+2), W1(g+2)     -- A one tile ahead, W a tile and a half
+    // Slot reuse (WAR): every memory part drains its ds_reads (lgkmcnt(0)) before its barrier; the W slots are refilled in
+    // phase b, one barrier after the other group's phase-a reads, the A slots in phase a of the next tile.  Arrival (RAW):
+    // the counted vmcnt in phase b retires everything but the two W halves just issued; both groups have passed that wait
+    // before either reads tile g+1.  (Four phases of 16 MFMAs each -- twice the barriers -- measured 1.48 us per K tile.)
     const int nk = K / PP_BK, total = n_my * nk;
     set_aoff(0); set_woff(0);
     issue_half(1, 0, 0, 0); issue_half(1, 1, 0, 0); issue_half(0, 0, 0, 0); issue_half(0, 1, 0, 0);
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 
     int g = 0;
     for (int seq = 0; seq < n_my; ++seq) {
+        PP_STAMP(0);
         for (int kt = 0; kt < nk; ++kt, ++g) {
             const int buf = g & 1;
             const unsigned char* la = lds + buf * PP_BUF_BYTES;
@@ -154,11 +162,14 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
             const bool more1 = g + 1 < total, more2 = g + 2 < total;
             const int kta = (kt + 1 == nk) ? 0 : kt + 1;                  // K tile the A stream fetches now
             const int ktw = (kt + 2 >= nk) ? kt + 2 - nk : kt + 2;        // ... and the W stream
-            // ---- P1: (h0, c0)
+            // ---- phase a: rows h0 x all 64 columns (32 MFMAs)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fb0[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
+                for (int ks = 0; ks < 2; ++ks) {
+                    fb0[j][ks] = ld16(lw + swz128(wc * 64 + j * 16 + lr, ks * 4 + lg));
+                    fb1[j][ks] = ld16(lw + swz128(wc * 64 + 32 + j * 16 + lr, ks * 4 + lg));
+                }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -166,21 +177,14 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
             if (more1) {
                 if (kt + 1 == nk) set_aoff(seq + 1);                      // the A stream moves on to the next output tile
                 issue_half(0, 0, kta, buf ^ 1);
+                issue_half(0, 1, kta, buf ^ 1);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // W(g) is read: its slots may be refilled in phase b
             __builtin_amdgcn_s_barrier();
             mfma_quadrant(0, fb0, 0);
-            __builtin_amdgcn_s_barrier();
-            // ---- P2: (h0, c1)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) fb1[j][ks] = ld16(lw + swz128(wc * 64 + 32 + j * 16 + lr, ks * 4 + lg));
-            if (more1) issue_half(0, 1, kta, buf ^ 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             mfma_quadrant(0, fb1, 1);
             __builtin_amdgcn_s_barrier();
-            // ---- P3: (h1, c1)
+            // ---- phase b: rows h1 x all 64 columns
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -188,24 +192,21 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
             if (more2) {
                 if (kt + 2 == nk) set_woff(seq + 1);                      // the W stream moves on to the next output tile
                 issue_half(1, 0, ktw, buf);
+                issue_half(1, 1, ktw, buf);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // A(g) is read: refilled from phase a of the next tile on
             __builtin_amdgcn_s_barrier();
             mfma_quadrant(1, fb1, 1);
-            __builtin_amdgcn_s_barrier();
-            // ---- P4: (h1, c0)
-            if (more2) { issue_half(1, 1, ktw, buf); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
             mfma_quadrant(1, fb0, 0);
             __builtin_amdgcn_s_barrier();
         }
 
-        // ---- epilogue of output tile seq: the wave's 128 x 64 accumulator tile goes through its own 4 KiB of LDS sixteen
-        // rows at a time.  The two wave groups run it side by side (the first group waits one barrier for the second and
-        // they re-stagger afterwards): coupled through the phase barriers, one group's epilogue would otherwise stall the
-        // other group's MFMAs and the two epilogues would run back to back.  A lane keeps one column group for all its
-        // items, so the column operands (bias) are loaded once per tile.
+        PP_STAMP(1);
         if (wr == 0) __builtin_amdgcn_s_barrier();
+        PP_STAMP(2);
         {
             int m0, n0; tile_origin(seq, m0, n0);
             const int nbase = n0 + wc * 64;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        PP_STAMP(3);
         if (wr == 1 && seq + 1 < n_my) __builtin_amdgcn_s_barrier();      // stagger again for the next tile
     }
 }
