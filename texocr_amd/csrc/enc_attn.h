@@ -196,6 +196,15 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 // q,k,v: bf16 head-major [B*heads][N][64].  Bound: MFMA bf16 (2.5 PF peak), in practice softmax VALU ~ MFMA time.
 constexpr int EAB_VT_STRIDE = 136;   // bytes per Vt row: 64 keys * 2 B + 8 pad (ds_read_b64 conflict-free across 16 rows)
 
+// two f32 -> packed bf16 pair (lo = a, hi = b) in one v_cvt_pk_bf16_f32
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ inline unsigned pack_bf16x2(float a, float b) {
+    const bf16x2_t h = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+    return __builtin_bit_cast(unsigned, h);
+}
+constexpr float LOG2E = 1.4426950408889634f;
+
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
                                                             const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads) {
@@ -209,7 +218,8 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
     const bf16* Kb = Kg + (size_t)bh * N * DH;
     const bf16* Vb = Vg + (size_t)bh * N * DH;
 
-    // Q fragments: lane (query lc, group lg) holds Q[query][32ks + 8lg .. +7], pre-scaled by 0.125 (exact in bf16)
+    // Q fragments: lane (query lc, group lg) holds Q[query][32ks + 8lg .. +7], pre-scaled by 0.125 * log2(e): the scores come
+    // out in base-2 units, so the softmax needs one v_exp_f32 per score and no multiply
     u32x4 qf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -222,8 +232,8 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 union { bf16 h[2]; unsigned u; } c;
-                c.h[0] = __float2bfloat16(__uint_as_float(w[k] << 16) * ATTN_SCALE);
-                c.h[1] = __float2bfloat16(__uint_as_float(w[k] & 0xffff0000u) * ATTN_SCALE);
+                c.h[0] = __float2bfloat16(__uint_as_float(w[k] << 16) * (ATTN_SCALE * LOG2E));
+                c.h[1] = __float2bfloat16(__uint_as_float(w[k] & 0xffff0000u) * (ATTN_SCALE * LOG2E));
                 o[k] = c.u;
             }
             qf[qt][ks] = u32x4{o[0], o[1], o[2], o[3]};
@@ -308,7 +318,7 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
             mx = grp4_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = expf(m_run[qt] - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
             m_run[qt] = m_new;
             float ps = 0.f;
             unsigned pk[8];
@@ -316,13 +326,10 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
             for (int kt = 0; kt < 4; ++kt) {
                 float p[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p[r] = expf(sc[qt][kt][r] - m_new); }
-                union { bf16 h[2]; unsigned u; } c0, c1;
-                c0.h[0] = __float2bfloat16(p[0]); c0.h[1] = __float2bfloat16(p[1]);
-                c1.h[0] = __float2bfloat16(p[2]); c1.h[1] = __float2bfloat16(p[3]);
-                // the normaliser sums what the MFMA will actually multiply (the bf16-rounded probabilities)
-                ps += (__bfloat162float(c0.h[0]) + __bfloat162float(c0.h[1])) + (__bfloat162float(c1.h[0]) + __bfloat162float(c1.h[1]));
-                pk[2 * kt] = c0.u; pk[2 * kt + 1] = c1.u;
+                for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[qt][kt][r] - m_new); }
+                // packed hardware conversion (v_cvt_pk_bf16_f32, round to nearest even); the normaliser is summed in f32
+                pk[2 * kt] = pack_bf16x2(p[0], p[1]); pk[2 * kt + 1] = pack_bf16x2(p[2], p[3]);
+                ps += (p[0] + p[1]) + (p[2] + p[3]);
             }
             pb[qt][0] = u32x4{pk[0], pk[1], pk[2], pk[3]};     // key tiles 0,1 -> k-step 0
             pb[qt][1] = u32x4{pk[4], pk[5], pk[6], pk[7]};     // key tiles 2,3 -> k-step 1
