@@ -92,7 +92,8 @@ struct Engine : EngineBase {
     // ----- device weights -----
     std::vector<void*> allocs;
     struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr; };
-    struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr; };
+    struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr;
+                  T* w1_16 = nullptr; float* b1_16 = nullptr; };   // decoder, wide rows: second copy interleaved by 16 (large-batch FFN-in)
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
     // hybrid ResNetV2 embedder: standardised conv weights as [oc][kh][kw][ic] of T, GroupNorm affine fp32
     struct GnW { float* g = nullptr; float* b = nullptr; };
@@ -109,7 +110,7 @@ struct Engine : EngineBase {
     float *ex = nullptr, *ey = nullptr, *eqkv = nullptr, *eenc = nullptr; T *ez = nullptr, *eao = nullptr, *ehid = nullptr;
     T* enc_t = nullptr;               // bf16 copy of the encoder output (A operand of the cross K/V GEMM)
     T *ckv = nullptr, *skv = nullptr;  // cross [Ld][2][B*h][N][64], self [Ld][2][B*h][Tmax][64]
-    float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr;
+    float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr, *dz = nullptr;
     int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
     // ----- decode session -----
     // A decode runs as 1..MAXL independent "lanes" (contiguous row ranges of the batch), each on its own HIP
@@ -263,6 +264,10 @@ struct Engine : EngineBase {
         if (int r = upload_T(&w->w1, interleave(w1->data, F, D, G))) return r;
         if (int r = upload_f32(&w->b1, interleave(b1->data, F, 1, G))) return r;
         if (int r = upload_T(&w->w2, w2->data)) return r;
+        if (G == 8 && D >= 512) {       // see enqueue_step: FFN-in of wide decoders at >= 128 rows goes through the large-GEMM kernel
+            if (int r = upload_T(&w->w1_16, interleave(w1->data, F, D, 16))) return r;
+            if (int r = upload_f32(&w->b1_16, interleave(b1->data, F, 1, 16))) return r;
+        }
         return upload_f32(&w->b2, b2->data);
     }
 
@@ -438,6 +443,7 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dq, (size_t)Bmax * Imax)) return r;
         if (int r = dalloc(&dao, (size_t)Bmax * Imax)) return r;
         if (int r = dalloc(&dhid, (size_t)Bmax * Fmax)) return r;
+        if (int r = dalloc(&dz, (size_t)Bmax * D)) return r;
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
@@ -764,9 +770,17 @@ struct Engine : EngineBase {
                 dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
-                DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = ly; a.x_out = lx;
-                a.h_out = lhid; a.F = Fd;
-                if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
+                if (sizeof(T) == 2 && nb >= 128 && dec_mlp[l].w1_16) {
+                    // perf mode, wide rows (ViT-Base decoder: 768), >= 128 rows: the 16-row launch would be 3072 blocks that each
+                    // redo the LayerNorm sandwich of their rows (39 us); one LayerNorm launch + the 128x128 GEMM takes ~15 us.
+                    // (fp32 parity mode keeps the 16-row kernel at every batch size: a row's bits never depend on the batch.)
+                    launch_ln<1>(s, ly, lx, dz + r0 * D, dec_g, dec_b, nb);
+                    launch_gemm_big<T>(s, LoadPlain<T>{dz + r0 * D, D}, dec_mlp[l].w1_16, nb, 2 * Fd, D, EpiGeglu<T>{lhid, dec_mlp[l].b1_16, Fd});
+                } else {
+                    DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = ly; a.x_out = lx;
+                    a.h_out = lhid; a.F = Fd;
+                    if (int r = launch_dec_gemm<PRO_LN2, EPI_GEGLU>(s, a)) return r;
+                }
                 dbg(s, "ffn1", l);
                 DecGemmArgs<T> g = base; g.N = D; g.K = Fd; g.W = dec_mlp[l].w2; g.bias = dec_mlp[l].b2; g.A = lhid;
                 g.resid = lx; g.y_out = ly;
