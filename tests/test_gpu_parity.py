@@ -535,6 +535,15 @@ def test_bf16_dma_gemm_bit_identical_to_register_staged(monkeypatch):
     ref = b_old.encoder(img)
     for _ in range(15):
         assert torch.equal(b_new.encoder(img), ref)
+    # default-factory model: the hybrid embedder's 1x1 projection (position rows added in the epilogue, K = 1024)
+    from texocr_amd.config import reference_config
+    dh = Dims.from_config(reference_config())
+    imgh = torch.from_numpy(synth.synth_images(4, 1, 160, 1008, seed=92)).cuda()
+    monkeypatch.setenv("TXO_GEMM_OLD", "1")
+    _, _, h_old = build(dh, seed=8, dtype="bf16", max_batch=4)
+    monkeypatch.delenv("TXO_GEMM_OLD")
+    _, _, h_new = build(dh, seed=8, dtype="bf16", max_batch=4)
+    assert torch.equal(h_new.encoder(imgh), h_old.encoder(imgh))
 
 
 def test_wide_decoder_large_batch_ffn_path():
