@@ -87,3 +87,20 @@ def test_product_does_not_import_oracle():
                 elif isinstance(node, ast.ImportFrom):
                     names = [node.module or ""]
                 assert not any(n.split(".")[0] == "oracle" for n in names), fn
+
+
+def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+    """The boundary is a C ABI: the header compiles as C99 and a C program links against the library and gets the documented
+    status code + message for an invalid configuration (no GPU needed: validation precedes any HIP call)."""
+    import shutil, subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(root, "include", "texocr.h")], check=True)
+    exe = str(tmp_path / "abi_demo")
+    libdir = os.path.join(root, "texocr_amd")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "abi_demo.c"),
+                    "-L" + libdir, "-ltexocr_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "texocr-amd" in out and "-> -1" in out and "embed_dim" in out
