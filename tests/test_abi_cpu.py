@@ -89,7 +89,7 @@ def test_product_does_not_import_oracle():
                 assert not any(n.split(".")[0] == "oracle" for n in names), fn
 
 
-def test_header_is_plain_c_and_a_c_program_links(tmp_path):
+def test_header_is_plain_c_and_a_c_program_links(lib, tmp_path):
     """The boundary is a C ABI: the header compiles as C99 and a C program links against the library and gets the documented
     status code + message for an invalid configuration (no GPU needed: validation precedes any HIP call)."""
     import shutil, subprocess
