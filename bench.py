@@ -165,7 +165,7 @@ def main():
             algo = a.batch * dims.dec_heads * 2 * N * 64 * esz
             traffic = None                      # PMC bytes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 passes
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bf16_b64.json")))["cross_attention_traffic"]
+                pm = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{a.dtype}_b64.json")))["cross_attention_traffic"]
                 if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N}:
                     traffic = pm["traffic_bytes"]
             except Exception:

@@ -1,0 +1,31 @@
+"""Summarise the rocprofv3 --pmc passes of probes/collect_pmc.sh: average FETCH_SIZE / WRITE_SIZE (KB) per launch of every kernel and
+the corrected HBM bytes of the cross-attention launch (gfx950 reports half the bytes of 16-B/lane streaming reads in FETCH_SIZE:
+MI355X_MICROARCH.md, HBM section -> read bytes = 2 * FETCH_SIZE * 1024).  python probes/pmc_summary.py <dir> <dtype>"""
+import csv, glob, json, sys
+from collections import defaultdict
+
+root, dtype = sys.argv[1], sys.argv[2]
+acc = defaultdict(lambda: defaultdict(list))
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(f"{root}/{counter}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"].split("(")[0]][counter].append(float(r["Counter_Value"]))
+B, heads, N, esz = 64, 8, 589, (2 if dtype == "bf16" else 4)
+kernels, cross = {}, None
+for name, c in sorted(acc.items()):
+    if "txo::" not in name:
+        continue
+    e = {"FETCH_SIZE_KB_avg": round(sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"])), 1),
+         "WRITE_SIZE_KB_avg": round(sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])), 1), "launches": len(c["FETCH_SIZE"])}
+    if "dec_attn_kernel" in name and ", 0, 1, 20," in name:          # cross attention (MODE 0, APRO_LN2, NL 20)
+        e["algorithmic_bytes_per_launch"] = B * heads * 2 * N * 64 * esz
+        e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
+        cross = (name, e)
+    kernels[name] = e
+out = {"note": "rocprofv3 --pmc <counter> --kernel-trace, separate passes (probes/collect_pmc.sh), bench.py --steps 1 --max-len 24 "
+               f"(B=64, {dtype}, 3x224x672). FETCH_SIZE/WRITE_SIZE are in KB; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950 correction).",
+       "cross_attention_traffic": {"config": {"batch": B, "dtype": dtype, "tokens": N}, "kernel": cross[0],
+                                   "traffic_bytes": cross[1]["hbm_bytes_per_launch_corrected"]},
+       "kernels": kernels}
+print(json.dumps(out, indent=1, sort_keys=True))
