@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--settle-seconds", type=float, default=1.5,
                     help="untimed: repeat the step for this long before the W warmup steps so that a freshly started GPU "
                          "reaches its steady clocks (the first process on a fresh box measured 8 %% slower without it)")
@@ -146,6 +146,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000 * elapsed / a.steps, 3),
             "p50_latency_ms": round(1000 * lat[len(lat) // 2], 3),
+            "p90_latency_ms": round(1000 * lat[min(len(lat) - 1, (9 * len(lat)) // 10)], 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic U[0,1) images, deterministic random-init weights (texocr_amd.synth seed 0)",
             "config": {"workload": f"BASELINE configs[1]: config.yml dims (256-d/8h/4L enc + 4L dec, patch 16, PatchEmbedding C=3), "
