@@ -30,6 +30,12 @@ namespace txo {
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
+// inside a bool lambda: records the failure (look_failed) and returns false
+#define HIP_TRY_B(expr)                                                                                 \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) { (void)fail(TXO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); look_failed = true; return false; } \
+    } while (0)
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t _e = (expr);                                                                         \
@@ -129,6 +135,9 @@ struct Engine : EngineBase {
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
+    int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
+    hipEvent_t ev_flags[MAXL] = {};
+    bool look_failed = false;
     int step_host_t = -1;             // position of the step being enqueued when the host knows it (see enqueue_step)
     // TXO_STAMPS=<file>: diagnostic -- every decode launch of ONE step records per-block entry / mid / exit times
     unsigned long long* stamp_buf = nullptr; int stamp_slot = -1; static constexpr int STAMP_BLOCKS = 2048, STAMP_KERNELS = 64;
@@ -163,6 +172,8 @@ struct Engine : EngineBase {
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_flags) if (e) (void)hipEventDestroy(e);
+        if (flags_host) (void)hipHostFree(flags_host);
         for (void* p : allocs) (void)hipFree(p);
     }
 
@@ -411,6 +422,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
+        for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_flags[i], hipEventDisableTiming));
         return 0;
     }
     int init_buffers() {
@@ -893,9 +905,27 @@ struct Engine : EngineBase {
         }
         int64_t* tdst = use_graph ? tok_buf : tokens_out;
         const int tstride = use_graph ? Tmax : max_len;
-        std::vector<int> flags((size_t)MAXL * Tmax, 0);
-        const int CHUNK = 32;
+        // GLOBAL eos break (decoder.py:115-116): the device records done_flag[t]; the host looks at the flags of every 32 steps.
+        // The look must not drain the stream: the flags of a chunk are copied to pinned memory behind the chunk, a few more
+        // steps are enqueued, and only then the host waits for that copy -- the GPU keeps running those steps meanwhile (a
+        // full stream sync at every chunk left it idle for the host's wake-up + re-enqueue time: 1.2 ms per 256 steps).  After
+        // a break at most AHEAD extra steps have run; their tokens lie beyond `steps` and are never returned.
+        const int CHUNK = 32, AHEAD = 4;
+        if (!flags_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flags_host), sizeof(int) * MAXL * Tmax, hipHostMallocDefault));
+        int* flags = flags_host;
         int steps = max_len;
+        look_failed = false;
+        int pend_lo = -1, pend_hi = -1;                            // chunk whose flags are in flight to the host
+        auto look = [&]() -> bool {                                // wait for the pending chunk's flags; true = all rows done
+            for (int i = 0; i < n_lanes; ++i) HIP_TRY_B(hipEventSynchronize(ev_flags[i]));
+            for (int k = pend_lo; k <= pend_hi; ++k) {
+                bool all = true;
+                for (int i = 0; i < n_lanes; ++i) all = all && flags[(size_t)i * Tmax + k];
+                if (all) { steps = k + 1; pend_lo = -1; return true; }
+            }
+            pend_lo = -1;
+            return false;
+        };
         const char* stamp_file = getenv("TXO_STAMPS");
         if (stamp_file && !stamp_buf) { if (int r = dalloc(&stamp_buf, (size_t)STAMP_KERNELS * STAMP_BLOCKS * 3)) return r; }
         const int stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
@@ -906,19 +936,17 @@ struct Engine : EngineBase {
                 if (use_graph) HIP_TRY(hipGraphLaunch(lanes[i].exec, lanes[i].stream));
                 else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos, nullptr, t)) return r2;
             }
-            if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
+            if (eos < 0) continue;
+            if (pend_lo >= 0 && (t == pend_hi + AHEAD || t + 1 == max_len)) { if (look()) break; if (look_failed) return TXO_E_HIP; }
+            if ((t + 1) % CHUNK == 0 || t + 1 == max_len) {
                 const int lo = (t / CHUNK) * CHUNK;
-                for (int i = 0; i < n_lanes; ++i)
-                    HIP_TRY(hipMemcpyAsync(flags.data() + (size_t)i * Tmax + lo, done_flag + (size_t)i * Tmax + lo,
+                for (int i = 0; i < n_lanes; ++i) {
+                    HIP_TRY(hipMemcpyAsync(flags + (size_t)i * Tmax + lo, done_flag + (size_t)i * Tmax + lo,
                                            sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, lanes[i].stream));
-                for (int i = 0; i < n_lanes; ++i) HIP_TRY(hipStreamSynchronize(lanes[i].stream));
-                bool stop = false;
-                for (int k = lo; k <= t && !stop; ++k) {
-                    bool all = true;
-                    for (int i = 0; i < n_lanes; ++i) all = all && flags[(size_t)i * Tmax + k];
-                    if (all) { steps = k + 1; stop = true; }
+                    HIP_TRY(hipEventRecord(ev_flags[i], lanes[i].stream));
                 }
-                if (stop) break;
+                pend_lo = lo; pend_hi = t;
+                if (t + 1 == max_len) { (void)look(); if (look_failed) return TXO_E_HIP; }
             }
         }
         // join the lanes back into the caller's stream
