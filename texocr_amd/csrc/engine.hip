@@ -891,7 +891,11 @@ struct Engine : EngineBase {
         // Measured on MI355X (B=64, 224x672, T=256): the step is bound by the GPU-side latency chain of its ~26
         // dependent launches, not by the host -- graph replay and 2-4 lanes give the same wall time as eager
         // single-stream launches (57.1 vs 58.0 / 58.2 ms) -- so both stay opt-in: TXO_GRAPH=1, TXO_LANES=n.
-        const bool eager = logits_out != nullptr || g_dbg || sample_mode || getenv("TXO_GRAPH") == nullptr;
+        // graph replay by default only for very small batches (B <= 4: there the host's enqueue rate bounds the step --
+        // 34.2 vs 37.2 ms per generate at B = 1 -- from B = 8 on it is equal); TXO_GRAPH=1 / 0 forces it on / off
+        const char* genv = getenv("TXO_GRAPH");
+        const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
+        const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
         int want = 1;
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
