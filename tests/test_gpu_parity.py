@@ -290,6 +290,14 @@ def test_full_size_batch_independence_and_determinism():
         finally:
             for k in env:
                 os.environ.pop(k)
+    # the fused-QKV self-attention variant (read at engine creation) is a different kernel: same tokens up to thin margins
+    os.environ["TXO_SELF_FUSED"] = "1"
+    try:
+        _, _, mfu = build(d, seed=0, max_batch=8, max_tokens=589)
+    finally:
+        os.environ.pop("TXO_SELF_FUSED")
+    tf = mfu.generate(img[:8].contiguous(), 64)
+    assert float((tf == t1[:8, :64]).float().mean()) > 0.98
     # bucketed variable-width input (BASELINE config 5's input shape): per-image rows equal the fixed-width result
     from texocr_amd.dist import generate_bucketed
     mixed = [img[0], img[1, :, :, :448].contiguous(), img[2], img[3, :, :, :448].contiguous()]
