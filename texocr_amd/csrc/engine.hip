@@ -986,20 +986,36 @@ struct Engine : EngineBase {
         const int n = std::max(rows, Tmax);
         hipLaunchKernelGGL(beam_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, cur_tok, bscore, bfin, done_flag, rows,
                            beams, Tmax, cfg.bos);
-        std::vector<int> flags(max_len, 0);
+        // same non-draining eos look as generate(): once every beam is finished further steps only repeat eos at no cost
+        // (beam_select_kernel), so the few steps enqueued ahead of the look change neither scores nor slots
+        if (!flags_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flags_host), sizeof(int) * MAXL * Tmax, hipHostMallocDefault));
+        int* flags = flags_host;
         int steps = max_len, cur = 0;
-        const int CHUNK = 32;
-        for (int t = 0; t < max_len; ++t) {
+        const int CHUNK = 32, AHEAD = 4;
+        int pend_lo = -1, pend_hi = -1;
+        bool stop = false;
+        for (int t = 0; t < max_len && !stop; ++t) {
             BeamCtx bm{beams, bpath[cur], bpath[cur ^ 1]};
             if (int r2 = enqueue_step(s, 0, nullptr, 0, nullptr, eos, &bm, t)) return r2;
             cur ^= 1;
-            if (eos >= 0 && ((t + 1) % CHUNK == 0 || t + 1 == max_len)) {
+            if (eos < 0) continue;
+            const bool last = t + 1 == max_len;
+            if ((t + 1) % CHUNK == 0 || last) {
+                if (pend_lo >= 0) {                                   // (only when CHUNK <= AHEAD; kept for safety)
+                    HIP_TRY(hipEventSynchronize(ev_flags[0]));
+                    for (int i = pend_lo; i <= pend_hi && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
+                    pend_lo = -1;
+                    if (stop) break;
+                }
                 const int lo = (t / CHUNK) * CHUNK;
-                HIP_TRY(hipMemcpyAsync(flags.data() + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipStreamSynchronize(s));
-                bool stop = false;
-                for (int i = lo; i <= t && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
-                if (stop) break;
+                HIP_TRY(hipMemcpyAsync(flags + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipEventRecord(ev_flags[0], s));
+                pend_lo = lo; pend_hi = t;
+            }
+            if (pend_lo >= 0 && (t == pend_hi + AHEAD || last)) {
+                HIP_TRY(hipEventSynchronize(ev_flags[0]));
+                for (int i = pend_lo; i <= pend_hi && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
+                pend_lo = -1;
             }
         }
         // backtrack every beam into tok_buf rows, then hand out the best beam (slot 0: selection order is by score)
