@@ -9,7 +9,8 @@
  * Conventions
  *   - every *_dev pointer is DEVICE memory owned by the caller; the engine owns its weight copy, KV caches
  *     and workspace (allocated in txo_engine_create, freed in txo_engine_destroy; no allocation in any
- *     encode/decode call);
+ *     encode/decode call -- the diagnostic modes TXO_STAMPS=<file> and txo_profile_enable(e, 1) are the exceptions: they
+ *     create their stamp buffer / HIP events on first use);
  *   - all work is enqueued on the caller's hipStream_t (`stream`, may be NULL = default stream) and is
  *     asynchronous except where noted; one engine per (device, stream); a handle is not thread-safe;
  *   - return value: 0 = ok, <0 = error (TXO_E_*); txo_last_error() returns a thread-local message;
@@ -123,6 +124,14 @@ int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint
  * kept for the first 16 generate() calls after enabling); on = 0: off. */
 int txo_profile_enable(txo_engine* e, int32_t on);
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count);
+
+/* Introspection for tests and bench.py.  what = TXO_Q_LAST_PERSISTENT: 1 if the last txo_generate* ran its decode loop as ONE
+ * persistent launch (texocr_amd/csrc/persist.h; greedy decode of the reference widths), 0 if it ran one launch per stage
+ * (sampling, beam search, profiling modes, other widths, TXO_PERSIST=0, or after a fallback).  TXO_Q_PERSIST_FALLBACKS: how
+ * many persistent launches gave up (placement check / bounded spin) and were redone with launches since the engine was created. */
+#define TXO_Q_LAST_PERSISTENT 0
+#define TXO_Q_PERSIST_FALLBACKS 1
+int txo_engine_query(txo_engine* e, int32_t what, int64_t* out);
 
 const char* txo_last_error(void);
 const char* txo_version(void);

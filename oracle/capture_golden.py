@@ -344,6 +344,82 @@ def cap_hybrid():
          tokens=toks.numpy().astype(np.int16), step_logits=step_logits.numpy(), margin=margins(step_logits))
 
 
+@torch.no_grad()
+def cap_cfg4():
+    """G10 / BASELINE config 4: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h: encoder and decoder widths
+    must match), 3x224x672 (N=589), B=2, 8 greedy steps from the reference (encoder.py:75-121, decoder.py:148-173)."""
+    d = Dims(canvas=672, embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6)
+    seed, img_seed = 0, 2468
+    model, sd = build_reference(d, seed)
+    img = torch.from_numpy(synth.synth_images(2, 3, 224, 672, img_seed))
+    enc = model.encoder(img)
+    with greedy_patch() as gp:
+        toks = model.generate(img, max_len=8)
+    step_logits = torch.stack(gp.logits, 1)
+    t5i, t5v = top5(step_logits)
+    print("   cfg4: min margin", float(margins(step_logits).min()))
+    save("cfg4_b2_224x672", {"dims": d.to_dict(), "weight_seed": seed, "image_seed": img_seed,
+                             "image_shape": [2, 3, 224, 672], "max_len": 8,
+                             "enc_rows_note": "enc_rows = enc[:, ::16, ::4] (every 16th token, every 4th feature)"},
+         enc_rows=enc[:, ::16, ::4].numpy(), enc_sum=enc.double().sum((1, 2)).numpy(),
+         enc_abs_sum=enc.double().abs().sum((1, 2)).numpy(),
+         tokens=toks.numpy().astype(np.int16), margin=margins(step_logits),
+         top5_ids=t5i, top5_vals=t5v, step_logits=step_logits.numpy())
+
+
+@torch.no_grad()
+def cap_wrapper():
+    """N3: the reference's TeXOCRWrapper.__call__ (ocr_model.py:94-110) on a drawn image, through the default factory
+    (hybrid embedder).  torchvision is absent, so the wrapper object is assembled by hand around the reference's own
+    create_model / RegExTokenizer / process_output, and its ``img_transform`` is the inference part of
+    data_wrangling/dataset.py:365-371 (ToTensor -> Grayscale(1) -> Invert, no RandomAffine) written with numpy.  Two calls:
+    one inside the positional table, one with max_len > max_length, where the reference slides its window
+    (decoder.py:99-100)."""
+    from PIL import Image, ImageDraw
+    from TeXOCR.model.ocr_model import TeXOCRWrapper as RefWrapper
+    from TeXOCR.tokenizer.tokenizer import RegExTokenizer as RefTok
+    cfg = reference_config(max_length=24)
+    cfg["device"] = "cpu"
+    tok = RefTok()
+    tok.load(os.path.join(REF, "tokenizer", "tokenizer_clean_1k.txt"))
+    cfg["vocab_size"] = tok.vocab_size
+    d = Dims.from_config(cfg)
+    model = ref_create_model({k: v for k, v in cfg.items() if k not in ("embed",)}).eval()
+    img = Image.new("RGB", (160, 48), (255, 255, 255))
+    dr = ImageDraw.Draw(img)
+    dr.line((10, 40, 60, 8), fill=(0, 0, 0), width=2)
+    dr.ellipse((70, 10, 110, 40), outline=(40, 40, 200), width=2)
+    dr.rectangle((120, 12, 150, 36), outline=(200, 30, 30), width=1)
+    pixels = np.asarray(img, dtype=np.uint8)
+
+    def transform(im):
+        a = np.asarray(im.convert("RGB"), dtype=np.float32) / 255.0
+        g = 0.2989 * a[..., 0] + 0.587 * a[..., 1] + 0.114 * a[..., 2]
+        return torch.from_numpy(np.ascontiguousarray(1.0 - g))[None]
+    w = object.__new__(RefWrapper)
+    w.tokenizer, w.model, w.img_transform = tok, model, transform
+    # random weights give razor-thin top-1/top-2 margins now and then (SURVEY H1): take the first weight seed whose
+    # smallest margin over both calls leaves room for fp32 reduction-order noise (~5e-6)
+    for seed in range(21, 60):
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(d, seed).items()})
+        out = {"pixels": pixels, "tensor": transform(img).numpy()}
+        meta = {"dims": d.to_dict(), "weight_seed": seed, "cases": []}
+        worst = 1e9
+        for name, max_len in (("inside", 20), ("sliding", 40)):
+            with greedy_patch() as gp:
+                toks, text = w(img, max_len=max_len)
+            m = margins(torch.stack(gp.logits, 1))
+            worst = min(worst, float(m.min()))
+            out[f"tokens_{name}"] = np.asarray(toks, dtype=np.int16)
+            out[f"margin_{name}"] = m[0]
+            meta["cases"].append({"name": name, "max_len": max_len, "text": text, "n_tokens": len(toks)})
+        print(f"   wrapper: weight seed {seed}: min margin {worst:.2e}")
+        if worst > 2e-3:
+            break
+    meta["min_margin"] = worst
+    save("wrapper_160x48", meta, **out)
+
+
 def cap_tokenizer():
     """N4: encode/decode vectors from the reference RegExTokenizer on its own vocabulary file (its merge table is
     exported as data to tests/golden/tokenizer_vocab_1k.json), and process_output (utils.py:73-79) known answers."""
@@ -366,7 +442,7 @@ def cap_tokenizer():
     print("[golden] tokenizer_cases.json", len(cases), "cases")
 
 
-CAPS = {"tokenizer": cap_tokenizer, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
+CAPS = {"tokenizer": cap_tokenizer, "cfg4": cap_cfg4, "wrapper": cap_wrapper, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
         "window": cap_window, "sampling": cap_sampling}
 
 if __name__ == "__main__":

@@ -571,3 +571,74 @@ def test_wide_decoder_large_batch_ffn_path():
     assert float((lb_big[:64] - lb_small).abs().max()) < 0.05
     assert float((lb_big.float() - lf).abs().max()) < 0.35
     assert float((lb_big[:64].argmax(-1) == lb_small.argmax(-1)).float().mean()) > 0.97
+
+
+# ------------------------------------------------------------------------------------------------
+# the decode loop as ONE persistent launch (csrc/persist.h) against the launch-per-stage path
+# ------------------------------------------------------------------------------------------------
+def _both_paths(m, img, max_len, **kw):
+    """generate() through the persistent launch (default) and with TXO_PERSIST=0; asserts which path ran."""
+    import os
+    out_p = m.generate(img, max_len, **kw)
+    assert m._engine.query(0) == 1, "the persistent launch did not run"
+    os.environ["TXO_PERSIST"] = "0"
+    try:
+        out_l = m.generate(img, max_len, **kw)
+        assert m._engine.query(0) == 0
+    finally:
+        os.environ.pop("TXO_PERSIST")
+    assert m._engine.query(1) == 0, "a persistent launch fell back to launches"
+    return out_p, out_l
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [1, 5, 64, 100])
+def test_persistent_decode_bit_identical_to_launches(dtype, B):
+    """Same tile functions, same reduction orders: tokens AND per-step logits are bit-identical for every batch
+    size (1 row in one team ... 13 rows in each of 8 teams with a ragged last one)."""
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=3, dtype=dtype, max_batch=B)
+    g = torch.Generator(device="cuda").manual_seed(77 + B)
+    img = torch.rand((B, 3, 64, 224), generator=g, device="cuda")
+    (tp, lp), (tl, ll) = _both_paths(m, img, 40, return_logits=True)
+    assert tp.shape == (B, 40)
+    assert torch.equal(tp, tl)
+    assert torch.equal(lp, ll)
+
+
+def test_persistent_decode_global_eos_break():
+    """Small vocabulary so that eos fires at different positions in different rows and teams: the persistent launch must
+    return exactly the columns of the reference's GLOBAL break (decoder.py:115-116), like the launch path and the oracle."""
+    cpu_ref = _oracle()
+    d = Dims(canvas=224, vocab=16, bos=14, eos=5, pad=15, max_len=256)
+    d, sd, m = build(d, seed=11, max_batch=20)
+    img = torch.from_numpy(synth.synth_images(20, 3, 32, 96, seed=5)).cuda()
+    # pick as eos a token that every row emits, the last row as late as possible (rows and teams finish at different positions)
+    m.eos_token = None
+    free = m.generate(img, 256).cpu().numpy()
+    best = None
+    for tok in range(d.vocab):
+        hit = free == tok
+        if hit.any(axis=1).all():
+            first = hit.argmax(axis=1)
+            if best is None or first.max() > best[1]:
+                best = (tok, int(first.max()), int(first.min()))
+    assert best is not None and best[1] > best[2] + 2, best
+    eos = best[0]
+    m.eos_token = eos
+    tp, tl = _both_paths(m, img, 256)
+    assert torch.equal(tp, tl)
+    ref = cpu_ref.generate_cached(cpu_ref.to_torch_sd(sd), img.cpu(), d.bos, eos, 256)
+    assert tp.shape[1] == best[1] + 1 and 1 < tp.shape[1] < 256, "the crafted case must break early"
+    assert tp.shape == tuple(ref.shape)
+    assert np.array_equal(tp.cpu().numpy(), ref.numpy())
+    assert np.array_equal(tp.cpu().numpy(), free[:, :tp.shape[1]])
+    assert bool((tp == eos).any(dim=1).all()) and not bool((tp[:, :-1] == eos).any(dim=1).all())
+    # eos_tok = None: never breaks
+    m.eos_token = None
+    assert m.generate(img, 48).shape == (20, 48) and m._engine.query(0) == 1
+    # bos == eos: the BOS column already satisfies the test -> one step (decoder.py:115 looks at the whole output)
+    d2 = Dims(canvas=224, vocab=16, bos=5, eos=5, pad=15, max_len=64)
+    d2, sd2, m2 = build(d2, seed=11, max_batch=20)
+    t2p, t2l = _both_paths(m2, img, 64)
+    assert t2p.shape == (20, 1) and torch.equal(t2p, t2l)

@@ -161,3 +161,41 @@ def test_hybrid_default_factory_every_stage():
     toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, meta["max_len"], collect_logits=True, enc=enc)
     assert np.array_equal(toks.numpy(), g["tokens"])
     np.testing.assert_allclose(logits.numpy(), g["step_logits"], atol=5e-5)
+
+
+def test_cfg4_vit_base_encoder_and_decode():
+    """G10 / BASELINE config 4: ViT-Base 12L/768d/12h encoder + 6L/768d/12h decoder, B=2, 224x672, 8 reference steps."""
+    meta, g = load_golden("cfg4_b2_224x672")
+    d, sd, img = model_of(meta)
+    assert (d.embed_dim, d.enc_layers, d.dec_layers, d.enc_heads) == (768, 12, 6, 12)
+    enc = cpu_ref.encode(sd, img)
+    assert enc.shape == (2, 589, 768)
+    np.testing.assert_allclose(enc[:, ::16, ::4].numpy(), g["enc_rows"], atol=5e-5)
+    np.testing.assert_allclose(enc.double().sum((1, 2)).numpy(), g["enc_sum"], rtol=0, atol=0.05)
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, 8, collect_logits=True, enc=enc)
+    assert float(g["margin"].min()) > 1e-2                    # a robust fixture: no razor-thin decisions
+    assert np.array_equal(toks.numpy(), g["tokens"])
+    np.testing.assert_allclose(logits.numpy(), g["step_logits"], atol=5e-5)
+
+
+def test_wrapper_fixture_preprocess_and_decode():
+    """N3: the oracle on the tensor the reference's wrapper fed its model (hybrid default factory), inside the
+    positional table and beyond it (the reference slides its window, decoder.py:99-100: recompute mode only);
+    the host-side pieces of the build's wrapper (preprocess, detokenise, process_output) against the same fixture."""
+    from PIL import Image
+    from texocr_amd.wrapper import preprocess_image
+    from texocr_amd.tokenizer import RegExTokenizer, process_output
+    import json, os
+    meta, g = load_golden("wrapper_160x48")
+    d = Dims(**meta["dims"])
+    x = preprocess_image(Image.fromarray(g["pixels"]))
+    assert np.array_equal(x.numpy(), g["tensor"])             # 48 x 160 are multiples of 16: no padding
+    sd = cpu_ref.to_torch_sd(synth.synth_state_dict(d, meta["weight_seed"]))
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_vocab_1k.json")))
+    tok = RegExTokenizer.from_tables(v["vocab_size"], v["special_tokens"], v["merges"])
+    for case in meta["cases"]:
+        t = cpu_ref.generate_recompute(sd, x[None], d.bos, d.eos, case["max_len"])
+        out = t[0].tolist()[:-1]                              # ocr_model.py:104
+        assert out == g[f"tokens_{case['name']}"].tolist(), case["name"]
+        assert process_output(tok.decode(out)) == case["text"]
+    assert meta["cases"][1]["max_len"] > d.max_len            # the second case really slides

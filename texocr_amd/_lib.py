@@ -37,6 +37,7 @@ SYMBOLS = {
     "txo_set_sampling": (C.c_int, [_P, _I, _I, C.c_float, C.c_uint64]),
     "txo_profile_enable": (C.c_int, [_P, _I]),
     "txo_profile_read": (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "txo_engine_query": (C.c_int, [_P, _I, C.POINTER(C.c_int64)]),
     "txo_last_error": (C.c_char_p, []),
     "txo_version": (C.c_char_p, []),
 }

@@ -24,6 +24,7 @@
 // Algorithmic bytes per launch = images*heads*2*len*64*sizeof(T).   Bound: HBM (8 TB/s peak).
 #pragma once
 #include "common.h"
+#include "dec_gemm.h"   // ldc_* coherent loads, NoWait
 
 namespace txo {
 
@@ -94,8 +95,22 @@ __device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX]
 // The hot loops are written WITHOUT data-dependent branches (clamped unconditional loads, masked scores of
 // -3e38 whose exp is exactly 0, selects): a guarded load becomes its own basic block and hipcc's waitcnt
 // insertion then falls back to vmcnt(0) per iteration, which serialises the whole K/V stream.
-template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false>
-__global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
+// LDS of one 256-thread group
+template <bool BEAM> struct DecAttnLds {
+    __attribute__((aligned(16))) float zs[768];   // normalised row
+    __attribute__((aligned(16))) float qkv[3][DH];
+    float part[4][DH];
+    float stat[12];
+    short pth[BEAM ? 1024 : 8];                   // beam: slot of every history position of this row
+};
+
+// One (image, head) pair `bh` by 256 threads (tid 0..255).  COH / wait_prev: see dec_gemm.h (persistent kernel); KV_EARLY:
+// the K panel does not depend on the previous stage (cross attention), so every wave except the one that polls the team
+// counter (tid < 64 of the workgroup's first group: a poll's wait would also wait for that wave's own panel) requests it
+// BEFORE the wait.  valid = false: same barriers, clamped addresses, no stores.
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM, bool COH, class Wait>
+__device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, int tid, DecAttnLds<BEAM>& L_, bool valid,
+                                              bool poll_wave, Wait&& wait_prev) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int LPR = DH / PER16;          // lanes per 64-element row: 16 (f32) / 8 (bf16)
     constexpr int KPI = 64 / LPR;            // keys per wave-instruction: 4 / 8
@@ -104,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     constexpr int NP = MODE == ATT_SELF ? 3 : 1;
     constexpr int NVMAX = 3;                 // row prologue: D <= 768 (one wave, float4 per lane per 256)
     constexpr int WMAX = 8;                  // weight pieces per thread per projection per group (bf16: one group at D = 256)
-    const int bh = blockIdx.x, img = bh / a.heads, head = bh - img * a.heads;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int img = bh / a.heads, head = bh - img * a.heads;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sub = lane % LPR, kq = lane / LPR;
     const int D = a.D, inner = a.heads * DH;
@@ -115,11 +130,8 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     T* Kb = a.K + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
     T* Vb = a.V + ((size_t)kvimg * a.heads + head) * a.lmax * DH;
 
-    __shared__ __attribute__((aligned(16))) float zs[768];   // normalised row
-    __shared__ short pth[BEAM ? 1024 : 1];                   // beam: slot of every history position of this row
-    __shared__ __attribute__((aligned(16))) float qkv[3][DH];
-    __shared__ float part[4][DH];
-    __shared__ float stat[12];
+    float (&zs)[768] = L_.zs; float (&qkv)[3][DH] = L_.qkv; float (&part)[4][DH] = L_.part; float (&stat)[12] = L_.stat;
+    short* pth = L_.pth;
 
     // ---- 0. projection weights: thread (d = tid>>2, prt = tid&3) owns 16-byte pieces prt, prt+4, ... of row d.
     //         Requested first: they depend on nothing and are needed first. ----
@@ -139,6 +151,8 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     if constexpr (FUSED) issue_w(0, 0);
 
     // ---- 1. request the K panel of the first pass ----
+    constexpr bool KV_EARLY = COH && MODE == ATT_CROSS && !BEAM;   // persistent kernel: the cross panel is older than the launch
+    if constexpr (!KV_EARLY) wait_prev();
     int t = 0;
     if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
     // cached keys: fused self handles the new key t apart; plain self finds it in the cache already
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     // cache policy: the cross panels (309 MB per step at batch 64) are streamed non-temporally so that they do not push
     // the decoder weights out of L2; the self-attention history (<= 67 MB over all layers) is re-read every step and
     // is read with the default policy (measured: self-attention launch 6.2 -> 5.4 us)
-    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF) return ld16(p); else return ld16_stream(p); };
+    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF) return ldc16<COH>(p); else return ld16_stream(p); };
     auto issue_k = [&](int base) {
 #pragma unroll
         for (int u = 0; u < NL; ++u) rk[u] = ld_kv(Kb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
@@ -171,7 +185,13 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
             for (int u = 0; u < NL; ++u) rv[u] = ld_kv(Vb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
         }
     };
-    issue_k(0);
+    if constexpr (KV_EARLY) {
+        if (!poll_wave) issue_k(0);
+        wait_prev();
+        if (poll_wave) issue_k(0);
+    } else {
+        issue_k(0);
+    }
 
     // ---- 2. row prologue (wave 0): x = LN(y) | emb ; z = LN(x) -> LDS ----
     if (FUSED && wave == 0) {
@@ -185,15 +205,15 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
                 g[i] = *reinterpret_cast<const float4*>(a.gamma + c);
                 b[i] = *reinterpret_cast<const float4*>(a.beta + c);
                 if constexpr (APRO == APRO_EMBED) {
-                    const float4 p = *reinterpret_cast<const float4*>(a.tok_emb + (size_t)a.tok[img] * D + c);
+                    const float4 p = *reinterpret_cast<const float4*>(a.tok_emb + (size_t)ldc_i64<COH>(a.tok + img) * D + c);
                     const float4 q = *reinterpret_cast<const float4*>(a.pos_emb + (size_t)t * D + c);
                     v[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
                 } else {
-                    v[i] = *reinterpret_cast<const float4*>(a.y + (size_t)img * D + c);
+                    v[i] = ldc_f4<COH>(a.y + (size_t)img * D + c);
                 }
             }
             if constexpr (APRO == APRO_LN2) ln64<NVMAX>(v, nv, g, b, inv_d);
-            if (head == 0) {
+            if (head == 0 && valid) {
 #pragma unroll
                 for (int i = 0; i < NVMAX; ++i) if (i < nv)
                     *reinterpret_cast<float4*>(a.x_out + (size_t)img * D + i * 256 + lane * 4) = v[i];
@@ -209,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
                 const int c = i * 64 + lane;
                 vals[i] = 0.f;
                 if (c < D) {
-                    if constexpr (APRO == APRO_EMBED) vals[i] = a.tok_emb[(size_t)a.tok[img] * D + c] + a.pos_emb[(size_t)t * D + c];
-                    else vals[i] = a.y[(size_t)img * D + c];
+                    if constexpr (APRO == APRO_EMBED) vals[i] = a.tok_emb[(size_t)ldc_i64<COH>(a.tok + img) * D + c] + a.pos_emb[(size_t)t * D + c];
+                    else vals[i] = ldc_f32<COH>(a.y + (size_t)img * D + c);
                 }
             }
             auto ln_narrow = [&]() {
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
                 }
             };
             if constexpr (APRO == APRO_LN2) ln_narrow();
-            if (head == 0) {
+            if (head == 0 && valid) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) if (i < ne) { const int c = i * 64 + lane; if (c < D) a.x_out[(size_t)img * D + c] = vals[i]; }
             }
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     float s_new = 0.f;                                        // self: score of the new key t
     if constexpr (MODE == ATT_SELF && FUSED) {
         // append k_t, v_t (rounded to the cache type, exactly what later steps will read back)
-        if (tid < 2 * DH) {
+        if (tid < 2 * DH && valid) {
             const int which = tid >> 6, dd = tid & 63;
             const T val = Elem<T>::from_f32(qkv[1 + which][dd]);
             (which ? Vb : Kb)[(size_t)t * DH + dd] = val;
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     float qv[PER16];
 #pragma unroll
     for (int e = 0; e < PER16; ++e)
-        qv[e] = (FUSED ? qkv[0][sub * PER16 + e] : a.qin[(size_t)img * inner + head * DH + sub * PER16 + e]) * ATTN_SCALE;
+        qv[e] = (FUSED ? qkv[0][sub * PER16 + e] : ldc_f32<COH>(a.qin + (size_t)img * inner + head * DH + sub * PER16 + e)) * ATTN_SCALE;
 
     // ---- 4. passes over the panel (one pass when len <= NL*KPB) ----
     float m_run = (MODE == ATT_SELF && FUSED) ? s_new : -3.0e38f, l_run = 0.f;
@@ -360,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     }
     if (lane == 0) stat[8 + wave] = l_run;
     __syncthreads();
-    if (tid < DH) {
+    if (tid < DH && valid) {
         float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         float l = (stat[8] + stat[9]) + (stat[10] + stat[11]);
         if constexpr (MODE == ATT_SELF && FUSED) {
@@ -371,9 +391,15 @@ __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
         a.out[(size_t)img * inner + head * DH + tid] = Elem<T>::from_f32(o / l);
     }
     if (a.stamps && tid == 0) {
-        unsigned long long* d = a.stamps + 3 * (size_t)blockIdx.x;
+        unsigned long long* d = a.stamps + 3 * (size_t)bh;
         d[0] = ts0; d[1] = ts1; d[2] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false>
+__global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
+    __shared__ DecAttnLds<BEAM> lds;
+    dec_attn_tile<T, MODE, APRO, NL, WB, NARROW, BEAM, false>(a, blockIdx.x, threadIdx.x, lds, true, false, NoWait{});
 }
 
 }  // namespace txo

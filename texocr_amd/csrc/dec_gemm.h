@@ -30,6 +30,36 @@ namespace txo {
 enum { PRO_NONE = 0, PRO_EMBED = 1, PRO_LN2 = 2, PRO_LNF = 3 };
 enum { EPI_QKV = 0, EPI_Q = 1, EPI_GLU_RES = 2, EPI_GEGLU = 3, EPI_BIAS_RES = 4, EPI_LOGITS = 5 };
 
+// ---- loads of data another workgroup of the SAME launch has written (persistent decode kernel, persist.h) ----
+// COH = true: the load must not be served by this CU's L1 (never refreshed by other CUs' stores): relaxed agent-scope
+// atomic loads compile to global_load_dword(x2) ... sc1, which the XCD's L2 serves.  COH = false: plain loads (every
+// launch-per-stage kernel: its inputs were written by earlier launches).
+template <bool COH> __device__ inline float ldc_f32(const float* p) {
+    if constexpr (!COH) return *p;
+    else return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COH> __device__ inline long long ldc_i64(const int64_t* p) {
+    if constexpr (!COH) return *p;
+    else return (long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH> __device__ inline u32x4 ldc16(const void* p) {
+    if constexpr (!COH) return ld16(p);
+    else {
+        const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+        const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32x4 r; r.x = (unsigned)lo; r.y = (unsigned)(lo >> 32); r.z = (unsigned)hi; r.w = (unsigned)(hi >> 32);
+        return r;
+    }
+}
+template <bool COH> __device__ inline float4 ldc_f4(const float* p) {
+    const u32x4 r = ldc16<COH>(p);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+// what a tile does between requesting its weights and touching the previous stage's output: nothing in a launch-per-stage
+// kernel (the launch boundary is the dependency); the persistent kernel waits for its team's arrival counter here
+struct NoWait { __device__ inline void operator()() const {} };
+
 template <typename T> struct DecGemmArgs {
     // problem
     int rows, N, K;                 // rows = batch, W is [N][K]
@@ -89,27 +119,33 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
 // fragment array has its exact size and every loop unrolls without guards: the run-time-K form of the LN-prologue
 // variants compiled to 110 branches and 324 VGPRs (one block per CU -- the 1024 blocks of the FFN-in launch at batch
 // 256 ran in four rounds, 17 us); the fixed form is straight-line code at <= 128 VGPRs.
-template <typename T, int PRO, int EPI, int KW, int BN = DG_BN>
-__global__ __launch_bounds__(256, (KW > 0 && KW <= 8 && (PRO == PRO_NONE || KW * 4 * Elem<T>::KCHUNK <= 256) ? 4 : 2))
-void dec_gemm_kernel(DecGemmArgs<T> a) {
+// One output tile (rows by*16.., columns bx*BN..) by 256 threads (tid 0..255; in the persistent kernel two such groups share
+// a 512-thread workgroup, each with its own `smem`).  valid = false: the group has no tile in this round -- it runs the same
+// barriers on clamped addresses and stores nothing.
+template <typename T, int PRO, int EPI, int KW, int BN, bool COH, class Wait>
+__device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem, bool valid,
+                                              Wait&& wait_prev) {
     // value/gate-paired epilogues (GLU, GeGLU) run on ONE 16-column tile whose weight rows are interleaved by 8
     // (8 value rows, then their 8 gate rows): lane lr < 8 holds the value, lane lr + 8 the gate of output n0/2 + lr
     constexpr bool PAIRED = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
     constexpr bool TWO = BN == 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
     constexpr bool FIXED = KW > 0;
     constexpr int GROUP = FIXED ? KW : DG_GROUP;              // k-chunks a wave keeps in flight at once
     constexpr int NVMAX = FIXED ? (KW * 4 * KCH) / 64 : 12;   // LN prologue: float4 per lane per row (row length 64 * nv)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     // the wave id must be PROVABLY wave-uniform: MFMA ignores EXEC, so a guard the compiler lowers to EXEC
     // masking (instead of a scalar branch) would still execute the MFMA on stale registers
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * DG_BM, n0 = blockIdx.x * BN;
+    const int m0 = by * DG_BM, n0 = bx * BN;
     const int K = FIXED ? KW * 4 * KCH : a.K, rows = a.rows;
     const int row_bytes = K * (int)sizeof(T);
-    const int pmask = min(16, row_bytes >> 4) - 1;
+    // XOR mask of the A-image swizzle: a power of two that DIVIDES the row's 16-byte piece count, so that piece ^ (r & pmask)
+    // stays inside the row for every width (24 pieces at K = 192 bf16 -> mask 7; a mask of 15 there sent the tail pieces
+    // into the next row's image)
+    const int npiece = row_bytes >> 4;
+    const int pmask = min(16, npiece & -npiece) - 1;
     unsigned long long ts0 = 0, ts1 = 0;
     if (a.stamps) ts0 = __builtin_amdgcn_s_memrealtime();
 
@@ -121,16 +157,9 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
     if constexpr (PAIRED) {
         e_b0 = a.bias[na];                                    // value bias (lr < 8) or gate bias (lr >= 8) of this lane's column
         if constexpr (TWO) e_b1 = a.bias[nb];
-        if constexpr (EPI == EPI_GLU_RES) {
-            e_res0 = a.resid[(size_t)emc * a.D + (n0 >> 1) + (lr & 7)];
-            if constexpr (TWO) e_res1 = a.resid[(size_t)emc * a.D + (n0 >> 1) + 8 + (lr & 7)];
-        }
     } else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_LOGITS) {
         e_b0 = a.bias[min(na, a.N - 1)]; e_b1 = a.bias[min(nb, a.N - 1)];
-        if constexpr (EPI == EPI_BIAS_RES) { e_res0 = a.resid[(size_t)emc * a.D + na]; e_res1 = a.resid[(size_t)emc * a.D + nb]; }
     }
-    int t = 0;
-    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
 
     // ---- weight fragments of the first group: issued before the prologue so they fly under it ----
     const int nch = K / KCH;                                  // 64-byte k-chunks per row
@@ -150,9 +179,19 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
         const int m = min(m0 + lr, rows - 1);
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
-            fa[c] = ld16(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+            fa[c] = ldc16<COH>(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
     };
     load_w(0);
+    // everything above is weights / biases; everything below reads what the previous stage produced
+    wait_prev();
+    if constexpr (EPI == EPI_GLU_RES) {
+        e_res0 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + (n0 >> 1) + (lr & 7));
+        if constexpr (TWO) e_res1 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + (n0 >> 1) + 8 + (lr & 7));
+    } else if constexpr (EPI == EPI_BIAS_RES) {
+        e_res0 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + na); e_res1 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + nb);
+    }
+    int t = 0;
+    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
     if constexpr (PRO == PRO_NONE) load_a_global(0);
     // keep every fragment load ahead of the first MFMA: with K fixed this is one basic block and the machine
     // scheduler would otherwise interleave loads and MFMAs four at a time (serialising the memory latency)
@@ -170,7 +209,7 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
             b[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
         }
         if constexpr (PRO == PRO_EMBED) {
-            const float* te = a.tok_emb + (size_t)a.tok[m] * K;
+            const float* te = a.tok_emb + (size_t)ldc_i64<COH>(a.tok + m) * K;
             const float* pe = a.pos_emb + (size_t)t * K;
 #pragma unroll
             for (int i = 0; i < NVMAX; ++i) if (i < nv) {
@@ -181,11 +220,11 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
         } else {
 #pragma unroll
             for (int i = 0; i < NVMAX; ++i) if (i < nv)
-                v[i] = *reinterpret_cast<const float4*>(a.y + (size_t)m * K + i * 64 + sub * 4);
+                v[i] = ldc_f4<COH>(a.y + (size_t)m * K + i * 64 + sub * 4);
         }
         if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, g, b, inv_d);
         if constexpr (PRO == PRO_EMBED || PRO == PRO_LN2) {
-            if (blockIdx.x == 0 && m0 + r < rows) {
+            if (bx == 0 && valid && m0 + r < rows) {
 #pragma unroll
                 for (int i = 0; i < NVMAX; ++i) if (i < nv)
                     *reinterpret_cast<float4*>(a.x_out + (size_t)m * K + i * 64 + sub * 4) = v[i];
@@ -235,7 +274,7 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
 
     // ------------------------------ epilogue ------------------------------
     if (a.stamps && tid == 0) {
-        unsigned long long* d = a.stamps + 3 * (size_t)(blockIdx.y * gridDim.x + blockIdx.x);
+        unsigned long long* d = a.stamps + 3 * (size_t)(by * ((a.N + BN - 1) / BN) + bx);
         d[0] = ts0; d[1] = ts1; d[2] = __builtin_amdgcn_s_memrealtime();
     }
     if constexpr (PAIRED) {
@@ -243,19 +282,18 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
         for (int h = 0; h < (TWO ? 2 : 1); ++h) {
             const float mine = (h ? c1 : c0) + (h ? e_b1 : e_b0);
             const float gate = __shfl_xor(mine, 8, 64);       // lane lr + 8 holds this output's gate (all lanes take part)
-            if (lr < 8 && em < rows) {
+            if (lr < 8 && em < rows && valid) {
                 const int j = (n0 >> 1) + 8 * h + lr;         // each 16 interleaved weight rows -> 8 outputs
                 if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoidf(gate) + (h ? e_res1 : e_res0);
                 else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(mine * gelu_erf(gate));
             }
         }
     } else {
-        if (em >= rows) return;
 #pragma unroll
         for (int h = 0; h < (TWO ? 2 : 1); ++h) {
             const int n = h ? nb : na;
             const float v = h ? c1 : c0;
-            if (n >= a.N) continue;
+            if (n >= a.N || em >= rows || !valid) continue;
             if constexpr (EPI == EPI_QKV || EPI == EPI_Q) {
                 const int which = n / a.inner, f = n - which * a.inner;
                 if (which == 0) a.q_out[(size_t)em * a.inner + f] = v;
@@ -270,6 +308,13 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
             }
         }
     }
+}
+
+template <typename T, int PRO, int EPI, int KW, int BN = DG_BN>
+__global__ __launch_bounds__(256, (KW > 0 && KW <= 8 && (PRO == PRO_NONE || KW * 4 * Elem<T>::KCHUNK <= 256) ? 4 : 2))
+void dec_gemm_kernel(DecGemmArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    dec_gemm_tile<T, PRO, EPI, KW, BN, false>(a, blockIdx.x, blockIdx.y, threadIdx.x, smem, true, NoWait{});
 }
 
 template <typename T>

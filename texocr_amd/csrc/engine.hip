@@ -22,6 +22,7 @@
 #include "enc_attn.h"
 #include "gemm_big.h"
 #include "gemm_pp.h"
+#include "persist.h"
 #include "rows.h"
 #include "step.h"
 
@@ -69,6 +70,7 @@ struct EngineBase {
                               int eos, int64_t* tokens_out, float* scores_out, int64_t* all_tokens_out, int* n_steps,
                               hipStream_t s) = 0;
     int sample_mode = 0, sample_topk = 0; float sample_temp = 1.f; unsigned long long sample_seed = 0;
+    virtual int query(int what, int64_t* out) = 0;
     virtual int profile_enable(int on) = 0;
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
 };
@@ -129,7 +131,7 @@ struct Engine : EngineBase {
         hipStream_t stream = nullptr;      // lane 0 runs on the caller's stream
         hipStream_t own = nullptr;         // engine-owned stream for lanes > 0
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        int gb0 = -1, gnb = -1, gN = -1, geos = -2;   // what the captured graph was built for
+        int gb0 = -1, gnb = -1, gN = -1, geos = -2, gsB = -1, gsImg = -1;   // what the captured graph was built for (the cache strides sB / sImg are baked into its launches)
     };
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
@@ -151,6 +153,10 @@ struct Engine : EngineBase {
     hipEvent_t ev_fork = nullptr, ev_join[MAXL] = {nullptr, nullptr, nullptr, nullptr};
     int64_t* tok_buf = nullptr;            // [Bmax][Tmax] generated ids (engine-owned so graphs do not bake user pointers)
     int sB = 0, sN = 0, sImg = 0; bool session = false;   // decode rows, encoder tokens, images behind the cross K/V cache
+    // persistent decode launch (persist.h): control block (device + pinned host copy), per-stage stamps of one position
+    PersistCtl* pctl = nullptr; PersistCtl* pctl_host = nullptr; unsigned long long* pstamps = nullptr;
+    int persist_fallbacks = 0;                            // launches that gave up (placement / time-out) and were redone with launches
+    bool last_persist = false;                            // the last generate() ran as ONE persistent launch
     // beam search state (rows = images * beams)
     float* bscore = nullptr; int* bfin = nullptr; short* bpath[2] = {nullptr, nullptr}; short* bparent = nullptr; int* btok = nullptr;
     struct BeamCtx { int k; const short* path_cur; short* path_nxt; };
@@ -174,6 +180,7 @@ struct Engine : EngineBase {
         for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_flags) if (e) (void)hipEventDestroy(e);
         if (flags_host) (void)hipHostFree(flags_host);
+        if (pctl_host) (void)hipHostFree(pctl_host);
         for (void* p : allocs) (void)hipFree(p);
     }
 
@@ -275,7 +282,7 @@ struct Engine : EngineBase {
         if (int r = upload_T(&w->w1, interleave(w1->data, F, D, G))) return r;
         if (int r = upload_f32(&w->b1, interleave(b1->data, F, 1, G))) return r;
         if (int r = upload_T(&w->w2, w2->data)) return r;
-        if (G == 8 && D >= 512) {       // see enqueue_step: FFN-in of wide decoders at >= 128 rows goes through the large-GEMM kernel
+        if (sizeof(T) == 2 && G == 8 && D >= 512) {       // see enqueue_step: FFN-in of wide decoders at >= 128 rows goes through the large-GEMM kernel
             if (int r = upload_T(&w->w1_16, interleave(w1->data, F, D, 16))) return r;
             if (int r = upload_f32(&w->b1_16, interleave(b1->data, F, 1, 16))) return r;
         }
@@ -417,6 +424,11 @@ struct Engine : EngineBase {
         if (int r = arena_begin(arena.off)) return r;
         if (int r = init_buffers()) return r;                 // pass 2: carve
         HIP_TRY(hipMemset(st, 0, sizeof(StepState) * MAXL));
+        // the self-attention cache starts as zeros: clamped loads may touch rows no step has written yet (fused self-attention
+        // at t = 0 multiplies such a row by p = 0, which must not meet NaN/Inf bit patterns of recycled memory)
+        HIP_TRY(hipMemset(skv, 0, sizeof(T) * (size_t)cfg.dec_layers * 2 * Bmax * Id * Tmax));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flags_host), sizeof(int) * MAXL * Tmax, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pctl_host), sizeof(PersistCtl), hipHostMallocDefault));
         max_lanes = MAXL;
         for (int i = 1; i < max_lanes; ++i) HIP_TRY(hipStreamCreateWithFlags(&lanes[i].own, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
@@ -468,6 +480,8 @@ struct Engine : EngineBase {
         if (int r = dalloc(&bpath[1], (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&bparent, (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&btok, (size_t)Bmax * Tmax)) return r;
+        if (int r = dalloc(&pctl, 1)) return r;
+        if (int r = dalloc(&pstamps, (size_t)PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS)) return r;
         return 0;
     }
 
@@ -846,7 +860,7 @@ struct Engine : EngineBase {
     // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
     int lane_graph(int li, int eos) {
         Lane& ln = lanes[li];
-        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos) return 0;
+        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg) return 0;
         if (ln.exec) { (void)hipGraphExecDestroy(ln.exec); ln.exec = nullptr; }
         if (ln.graph) { (void)hipGraphDestroy(ln.graph); ln.graph = nullptr; }
         hipStream_t cs = cap_stream;
@@ -856,7 +870,7 @@ struct Engine : EngineBase {
         if (r) return r;
         if (e != hipSuccess) return fail(TXO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         HIP_TRY(hipGraphInstantiate(&ln.exec, ln.graph, nullptr, nullptr, 0));
-        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos;
+        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg;
         return 0;
     }
 
@@ -876,6 +890,102 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
+    bool persist_usable() const {
+        if (const char* e = getenv("TXO_PERSIST")) { if (atoi(e) == 0) return false; }
+        if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
+        if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
+        if (D == 256 && cfg.dec_heads == 8) return true;
+        if (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2) return true;
+        return false;
+    }
+    template <int D_, int H_>
+    int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
+        const size_t lds = 2 * persist_group_lds<T, D_, H_>() + 16;
+        auto kern = decode_persist_kernel<T, D_, H_>;
+        static bool attr_set = false;
+        if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(PS_TEAMS * PS_TEAM_BLOCKS), dim3(PS_THREADS), lds, s, pa);
+        return 0;
+    }
+    // returns 0 (done), TXO_E_STATE (the launch gave up: redo with launches), or an error
+    int generate_persist(int B, int N, int max_len, int eos, int64_t* tokens_out, float* logits_out, int* n_steps, hipStream_t s) {
+        PersistArgs<T> pa{};
+        pa.B = B; pa.N = N; pa.V = V; pa.Ld = cfg.dec_layers; pa.Tmax = Tmax; pa.max_len = max_len; pa.eos = eos; pa.bos = cfg.bos;
+        for (int l = 0; l < cfg.dec_layers; ++l) {
+            PersistLayer<T>& L = pa.L[l];
+            L.wqkv = dec_self[l].wqkv; L.wo_s = dec_self[l].wo; L.bo_s = dec_self[l].bo;
+            L.wq_c = dec_cross[l].wq; L.wo_c = dec_cross[l].wo; L.bo_c = dec_cross[l].bo;
+            L.w1 = dec_mlp[l].w1; L.b1 = dec_mlp[l].b1; L.w2 = dec_mlp[l].w2; L.b2 = dec_mlp[l].b2;
+        }
+        pa.gamma = dec_g; pa.beta = dec_b; pa.gamma_f = decn_g; pa.beta_f = decn_b; pa.tok_emb = tok_emb; pa.pos_emb = pos_emb;
+        pa.blog = blog; pa.wlog = wlog;
+        pa.dx = dx; pa.dy = dy; pa.dq = dq; pa.dlogits = dlogits; pa.dao = dao; pa.dhid = dhid;
+        pa.cur_tok = cur_tok; pa.eos_seen = eos_seen; pa.skv = skv; pa.ckv = ckv;
+        pa.self_stride = (size_t)sB * Id * Tmax; pa.cross_stride = (size_t)sImg * N * Id;
+        pa.tokens_out = tokens_out; pa.out_stride = max_len; pa.logits_out = logits_out;
+        pa.ctl = pctl; pa.stamps = pstamps;
+        const char* stamp_file = getenv("TXO_PSTAMPS");
+        pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
+        HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
+        if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));
+        if (D == 256) { if (int r = launch_persist<256, 8>(pa, s)) return r; }
+        else if constexpr (sizeof(T) == 2) { if (int r = launch_persist<768, 12>(pa, s)) return r; }
+        else return TXO_E_STATE;
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(pctl_host, pctl, sizeof(PersistCtl), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const PersistCtl& c = *pctl_host;
+        if (c.fail) { g_err = c.fail & 2u ? "persistent decode: a team spans more than one XCD" : "persistent decode: a hand-off timed out"; return TXO_E_STATE; }
+        // GLOBAL eos break (decoder.py:115-116): the loop ends after the first position at which every row contains eos
+        const int rpt = (B + PS_TEAMS - 1) / PS_TEAMS, nteams = (B + rpt - 1) / rpt;
+        int steps = max_len;
+        if (eos >= 0) {
+            bool all = true; int last = 0;
+            for (int k = 0; k < nteams; ++k) {
+                const int nr = std::min(rpt, B - k * rpt);
+                all = all && (int)c.eos_rows[k] >= nr;
+                last = std::max(last, c.last_first_eos[k]);
+            }
+            if (all) steps = std::min(max_len, last + 1);
+        }
+        if (stamp_file) dump_persist_stamps(stamp_file, nteams);
+        *n_steps = steps;
+        return 0;
+    }
+    void dump_persist_stamps(const char* file, int nteams) {
+        const int ns = 7 * cfg.dec_layers + 2;
+        std::vector<unsigned long long> h((size_t)PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS);
+        if (hipMemcpy(h.data(), pstamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+        FILE* f = fopen(file, "w");
+        if (!f) return;
+        static const char* names[7] = {"LN+qkv gemm", "self attention", "self out-proj+GLU+res", "cross attention (LN+q fused)",
+                                       "cross out-proj+GLU+res", "LN+ffn-in+GeGLU", "ffn-out+res"};
+        static const int ranks[PS_STAMP_RANKS] = {0, 10, 20, PS_TEAM_BLOCKS - 1};
+        fprintf(f, "# persistent decode launch, ONE decode position, workgroups of rank 0 / 10 / 20 / 31 of every team.  Per stage, us:\n"
+                   "#   poll  = polling the team counter for the previous stage's arrivals (weights / K panel already requested)\n"
+                   "#   work  = barrier + read the previous stage's rows (sc1) + compute + issue the stores\n"
+                   "#   drain = s_waitcnt vmcnt(0) of every wave + workgroup barrier\n"
+                   "#   pub   = the arrival atomic, issued -> returned\n"
+                   "#   end   = time of publication since the position's first stamp\n");
+        for (int k = 0; k < nteams; ++k)
+            for (int r = 0; r < PS_STAMP_RANKS; ++r) {
+                const unsigned long long* d = &h[((size_t)k * PS_STAMP_RANKS + r) * PS_MAX_STAGES * PS_STAMP_WORDS];
+                if (!d[2]) continue;
+                const unsigned long long t0 = d[2];
+                fprintf(f, "team %d rank %d: position span %.2f us\n", k, ranks[r], (d[(ns - 1) * 5 + 4] - t0) / 100.0);
+                if (k > 1) continue;                           // the per-stage table for two teams is enough
+                for (int i = 0; i < ns; ++i) {
+                    const unsigned long long* e = d + i * 5;
+                    const char* nm = i < 7 * cfg.dec_layers ? names[i % 7] : (i == 7 * cfg.dec_layers ? "LNf+logits" : "argmax+append");
+                    fprintf(f, "  L%-2d %-30s poll %5.2f  work %5.2f  drain %5.2f  pub %5.2f | end %7.2f\n", i < 7 * cfg.dec_layers ? i / 7 : -1, nm,
+                            e[0] ? (e[1] - e[0]) / 100.0 : 0.0, e[1] ? (e[2] - e[1]) / 100.0 : 0.0, (e[3] - e[2]) / 100.0, (e[4] - e[3]) / 100.0,
+                            (e[4] - t0) / 100.0);
+                }
+            }
+        fclose(f);
+    }
+
     int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                  int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) override {
         if (max_len < 1) return fail(TXO_E_INVALID, "max_len must be >= 1");
@@ -887,6 +997,16 @@ struct Engine : EngineBase {
             enc = eenc; N = 1 + (H / 16) * (W / 16);
         }
         if (int r = decode_begin(enc, B, N, eos, s)) return r;   // eos also decides whether the BOS column counts
+        last_persist = false;
+        if (persist_usable()) {
+            int steps = 0;
+            const int pr = generate_persist(B, N, max_len, eos, tokens_out, logits_out, &steps, s);
+            if (pr == 0) { last_persist = true; if (n_steps) *n_steps = steps; return 0; }
+            if (pr != TXO_E_STATE) return pr;
+            ++persist_fallbacks;                                  // placement check or a bounded spin gave up: decode with launches
+            set_lanes(1, s);
+            reset_lanes(s, eos);
+        }
         // lanes: graphs + extra streams unless per-step logits were asked for or a debug/profiling mode is on
         // Measured on MI355X (B=64, 224x672, T=256): the step is bound by the GPU-side latency chain of its ~26
         // dependent launches, not by the host -- graph replay and 2-4 lanes give the same wall time as eager
@@ -901,7 +1021,7 @@ struct Engine : EngineBase {
         if (B < 32) want = 1;
         set_lanes(want, s);
         reset_lanes(s, eos);
-        bool use_graph = !eager && !prof;
+        bool use_graph = !eager && !prof && !prof_cross;   // event-carrying launches cannot be captured
         if (use_graph) for (int i = 0; i < n_lanes; ++i) if (int r = lane_graph(i, eos)) return r;
         if (n_lanes > 1) {
             HIP_TRY(hipEventRecord(ev_fork, s));
@@ -915,8 +1035,7 @@ struct Engine : EngineBase {
         // full stream sync at every chunk left it idle for the host's wake-up + re-enqueue time: 1.2 ms per 256 steps).  After
         // a break at most AHEAD extra steps have run; their tokens lie beyond `steps` and are never returned.
         const int CHUNK = 32, AHEAD = 4;
-        if (!flags_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flags_host), sizeof(int) * MAXL * Tmax, hipHostMallocDefault));
-        int* flags = flags_host;
+        int* flags = flags_host;                                   // pinned, allocated in init()
         int steps = max_len;
         look_failed = false;
         int pend_lo = -1, pend_hi = -1;                            // chunk whose flags are in flight to the host
@@ -988,7 +1107,6 @@ struct Engine : EngineBase {
                            beams, Tmax, cfg.bos);
         // same non-draining eos look as generate(): once every beam is finished further steps only repeat eos at no cost
         // (beam_select_kernel), so the few steps enqueued ahead of the look change neither scores nor slots
-        if (!flags_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&flags_host), sizeof(int) * MAXL * Tmax, hipHostMallocDefault));
         int* flags = flags_host;
         int steps = max_len, cur = 0;
         const int CHUNK = 32, AHEAD = 4;
@@ -1034,6 +1152,12 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    int query(int what, int64_t* out) override {
+        if (what == TXO_Q_LAST_PERSISTENT) *out = last_persist ? 1 : 0;
+        else if (what == TXO_Q_PERSIST_FALLBACKS) *out = persist_fallbacks;
+        else return fail(TXO_E_INVALID, "unknown query");
+        return 0;
+    }
     int profile_enable(int on) override {
         prof = on == 1; prof_cross = on == 2;
         ev_cross.clear(); ev_enc.clear(); ev_step.clear(); pool.used = 0;
@@ -1164,6 +1288,11 @@ int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint
 int txo_profile_enable(txo_engine* e, int32_t on) { return e ? e->impl->profile_enable(on) : fail(TXO_E_INVALID, "null engine"); }
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count) {
     return e ? e->impl->profile_read(kind, avg_ms, count) : fail(TXO_E_INVALID, "null engine");
+}
+
+int txo_engine_query(txo_engine* e, int32_t what, int64_t* out) {
+    if (!e || !out) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->query(what, out);
 }
 
 const char* txo_last_error(void) { return g_err.c_str(); }

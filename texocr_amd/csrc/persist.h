@@ -1,0 +1,330 @@
+// The whole greedy decode loop of AutoRegressiveDecoder.generate (reference model/decoder.py:97-116) as ONE persistent
+// launch: every decode position runs the same ~30 stages as the launch-per-stage path (engine.hip: enqueue_step), built
+// from the same tile functions (dec_gemm.h, dec_attn.h) and therefore bit-identical to it, but the dependency between two
+// stages is an in-launch hand-off instead of a kernel boundary.
+//
+// Why: at batch 64 a step is a chain of 30 dependent launches whose ~3.5 us each (boundary + launch ramp + cold operand
+// fetch) is 105 of its 173 us, while its HBM traffic needs ~58 us.  Inside one launch a stage
+//   * requests its weights BEFORE it waits for the previous stage (they do not depend on the chain), and
+//   * hands its rows over through the L2 it shares with its consumers (probes/team_seam.hip: 1.5 us per stage against
+//     3.1 us for an empty dependent launch).
+//
+// Geometry: 256 workgroups of 512 threads, one per CU, dealt into 8 TEAMS of 32 (team = blockIdx % 8: the dispatcher
+// places blocks b and b+8 on one XCD, which the kernel VERIFIES with HW_REG_XCC_ID before it trusts it).  A team owns a
+// contiguous range of batch rows for the whole decode; rows of different teams never interact (the reference's only
+// cross-row operation is the GLOBAL eos test, decoder.py:115-116, handled below), so there is no chip-wide barrier
+// anywhere.  A workgroup is two 256-thread groups; a stage's tiles / (image, head) pairs are dealt over the team's 64
+// groups.
+//
+// Hand-off (one per stage, all-to-all inside the team): every storing wave drains its stores (s_waitcnt vmcnt(0)),
+// workgroup barrier, ONE agent-scope atomic add on the team's arrival counter; a consumer polls that counter with sc1
+// loads from one lane, workgroup barrier, then reads the rows with sc1 loads (never from its CU's L1, which other CUs'
+// stores do not refresh; the XCD's L2 -- the coherence point of its 32 CUs -- serves them).  Stores are plain (they stay
+// in that L2).  This is valid only while producer and consumer share an XCD: each workgroup ORs its XCC id into a
+// per-team mask, and after the first hand-off every workgroup checks that its team's mask has ONE bit; otherwise the
+// launch gives up (ctl.fail) and the engine decodes with launches.  All spins are bounded (fail bit 0).
+//
+// GLOBAL eos break: a row handler counts first occurrences of eos per team; a team whose rows all contain eos sets its
+// bit in a chip-wide mask (memory-side atomic), and once the mask is full every team stops within two positions.  The
+// host derives n_steps from the per-team "position at which my last row first produced eos" exactly as the reference's
+// (output == eos).any(1).all() would; positions decoded beyond it are never returned.
+#pragma once
+#include "dec_attn.h"
+#include "dec_gemm.h"
+#include "step.h"
+
+namespace txo {
+
+constexpr int PS_TEAMS = 8, PS_TEAM_BLOCKS = 32, PS_THREADS = 512, PS_MAXLD = 8;
+constexpr int PS_MAX_STAGES = 7 * PS_MAXLD + 2, PS_STAMP_RANKS = 4, PS_STAMP_WORDS = 5;
+
+struct PersistCtl {                       // zeroed before every launch
+    unsigned counter[PS_TEAMS][32];       // arrival counters, a 128-byte line each
+    unsigned xcc_mask[PS_TEAMS];          // OR of (1 << XCC id) over the team's workgroups
+    unsigned eos_rows[PS_TEAMS];          // rows of the team that contain eos so far
+    int last_first_eos[PS_TEAMS];         // position at which a row of the team FIRST produced eos, maximum over rows
+    unsigned stop[PS_TEAMS];              // leave the loop (every active team is done)
+    int steps_run[PS_TEAMS];
+    unsigned done_mask;                   // teams whose rows all contain eos
+    unsigned fail;                        // bit 0: a spin timed out; bit 1: a team spans more than one XCD
+    unsigned pad[2];
+};
+static_assert(sizeof(PersistCtl) % 16 == 0, "memset block");
+
+template <typename T> struct PersistLayer {
+    const T* wqkv; const T* wo_s; const float* bo_s;          // self attention
+    const T* wq_c; const T* wo_c; const float* bo_c;          // cross attention (K/V projected once per generate)
+    const T* w1; const float* b1; const T* w2; const float* b2;
+};
+
+template <typename T> struct PersistArgs {
+    int B, N, V, Ld, Tmax, max_len, eos, bos;
+    PersistLayer<T> L[PS_MAXLD];
+    const float *gamma, *beta, *gamma_f, *beta_f, *tok_emb, *pos_emb, *blog;
+    const T* wlog;
+    float *dx, *dy, *dq, *dlogits; T *dao, *dhid;
+    int64_t* cur_tok; int* eos_seen;
+    T *skv, *ckv; size_t self_stride, cross_stride;           // per (layer, k|v) plane
+    int64_t* tokens_out; int out_stride; float* logits_out;
+    PersistCtl* ctl;
+    unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
+};
+
+// the team's arrival counter, seen from one workgroup
+struct TeamSync {
+    unsigned* cnt; unsigned target; unsigned* fail; int* lds_dead; bool armed, dead;
+    unsigned long long* stp;                                  // diagnostic: 5 ticks per stage (wait begin / end, drain begin / end, published)
+    __device__ inline void operator()() {                     // wait until every workgroup of the team has finished the previous stage
+        if (!armed) return;
+        armed = false;
+        if (threadIdx.x == 0) {
+            if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
+            unsigned spins = 0;
+            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(1);
+                if ((++spins & 1023u) == 0u) {                // ~ every 0.3 ms: give up after ~80 ms or when another workgroup has
+                    if (spins > (1u << 18) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                        atomicOr(fail, 1u); *lds_dead = 1; break;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (stp) stp[1] = __builtin_amdgcn_s_memrealtime();
+        }
+        __syncthreads();
+        dead = dead || *lds_dead != 0;
+    }
+    __device__ inline void arrive() {                         // this workgroup's part of the stage is in L2
+        if (stp && threadIdx.x == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (stp) stp[3] = __builtin_amdgcn_s_memrealtime();
+            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[4] = __builtin_amdgcn_s_memrealtime(); stp += 5; }
+        }
+        target += PS_TEAM_BLOCKS;
+        armed = true;
+    }
+};
+
+// KW (64-byte k-chunks per wave, dec_gemm.h) the launch path picks for a given K: same choice here -> same bits
+template <typename T> constexpr int ps_kw_pro(int K) { const int kw = K / (4 * Elem<T>::KCHUNK); return (kw == 2 || kw == 4 || kw == 6) ? kw : 0; }
+template <typename T> constexpr int ps_kw_half(int K) {
+    const int kw = K / (4 * Elem<T>::KCHUNK); return (kw == 4 || kw == 6 || kw == 8 || kw == 12 || kw == 16) ? kw : 0;
+}
+
+template <typename T, int D_, int HEADS_>
+constexpr size_t persist_group_lds() {
+    size_t g = (size_t)DG_BM * D_ * sizeof(T);                // LN-prologue A image (K = D)
+    if (g < 8192) g = 8192;                                   // cross-wave K reduction
+    if (g < sizeof(DecAttnLds<false>)) g = sizeof(DecAttnLds<false>);
+    return (g + 255) & ~(size_t)255;
+}
+
+template <typename T, int D_, int HEADS_>
+__global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<T> a) {
+    constexpr int D = D_, HEADS = HEADS_, ID = HEADS * DH, F = 4 * D;
+    constexpr size_t GLDS = persist_group_lds<T, D_, HEADS_>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const int team = blockIdx.x % PS_TEAMS, rank = blockIdx.x / PS_TEAMS;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
+    unsigned char* smem = smem_all + (size_t)grp * GLDS;
+    int* lds_dead = reinterpret_cast<int*>(smem_all + 2 * GLDS);
+    const int sb = rank * 2 + grp;                            // this group among the team's 64
+    constexpr int NSB = PS_TEAM_BLOCKS * 2;
+
+    // rows of this team
+    const int rpt = (a.B + PS_TEAMS - 1) / PS_TEAMS;
+    const int r0 = team * rpt, nr = max(0, min(a.B - r0, rpt));
+    if (nr == 0) return;                                      // whole team: nothing to do, nobody waits for it
+    const int nteams = (a.B + rpt - 1) / rpt;
+    const unsigned full_mask = (1u << nteams) - 1u;
+    const int nrt = (nr + DG_BM - 1) / DG_BM;                 // 16-row tiles
+
+    PersistCtl* ctl = a.ctl;
+    if (threadIdx.x == 0) {
+        *lds_dead = 0;
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        atomicOr(&ctl->xcc_mask[team], 1u << (id & 15u));
+        if (rank == 0 && a.eos >= 0 && a.bos == a.eos) {      // BOS already is eos: every row "contains eos" (decoder.py:115)
+            __hip_atomic_store(&ctl->eos_rows[team], (unsigned)nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    TeamSync ts{&ctl->counter[team][0], 0u, &ctl->fail, lds_dead, false, false, nullptr};
+    bool placement_checked = false;
+
+    DecGemmArgs<T> gb{};
+    gb.rows = nr; gb.gamma = a.gamma; gb.beta = a.beta; gb.t_ptr = nullptr; gb.D = D; gb.inner = ID; gb.heads = HEADS; gb.tmax = a.Tmax;
+    float* lx = a.dx + (size_t)r0 * D; float* ly = a.dy + (size_t)r0 * D; float* lq = a.dq + (size_t)r0 * ID;
+    T* lao = a.dao + (size_t)r0 * ID; T* lhid = a.dhid + (size_t)r0 * F; float* llog = a.dlogits + (size_t)r0 * a.V;
+    const bool poll_wave = threadIdx.x < 64;
+    const int srank = rank == 0 ? 0 : (rank == 10 ? 1 : (rank == 20 ? 2 : (rank == PS_TEAM_BLOCKS - 1 ? 3 : -1)));
+    unsigned long long* stamp_base = (a.stamps && srank >= 0 && threadIdx.x == 0)
+        ? a.stamps + ((size_t)team * PS_STAMP_RANKS + srank) * PS_MAX_STAGES * PS_STAMP_WORDS : nullptr;
+
+    int t = 0;
+    for (; t < a.max_len; ++t) {
+        gb.t_host = t;
+        int stage = 0;
+        ts.stp = (stamp_base && t == a.stamp_step) ? stamp_base : nullptr;
+        // one GEMM stage: tiles (bx, by) dealt over the team's groups; a workgroup with no tile only synchronises
+#define PS_GEMM(PRO, EPI, KW, BN, ARGS, NCOL)                                                                           \
+        do {                                                                                                            \
+            const int ncol_ = (NCOL), nt_ = ncol_ * nrt;                                                                \
+            for (int base_ = 0; base_ < nt_; base_ += NSB) {                                                            \
+                if (base_ > 0) __syncthreads();          /* the previous round's LDS reads are done */                  \
+                if (base_ + rank * 2 < nt_) {                                                                           \
+                    const int tile_ = base_ + sb; const bool ok_ = tile_ < nt_; const int tc_ = ok_ ? tile_ : nt_ - 1;  \
+                    dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts);       \
+                }                                                                                                       \
+            }                                                                                                           \
+            ts();                                                                                                       \
+            ts.arrive();                                                                                                \
+            ++stage;                                                                                                    \
+        } while (0)
+#define PS_ATTN(MODE, APRO, NLV, ARGS)                                                                                  \
+        do {                                                                                                            \
+            const int np_ = nr * HEADS;                                                                                 \
+            for (int base_ = 0; base_ < np_; base_ += NSB) {                                                            \
+                if (base_ > 0) __syncthreads();                                                                         \
+                if (base_ + rank * 2 < np_) {                                                                           \
+                    const int p_ = base_ + sb; const bool ok_ = p_ < np_;                                               \
+                    dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid,             \
+                        *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts);                               \
+                }                                                                                                       \
+            }                                                                                                           \
+            ts();                                                                                                       \
+            ts.arrive();                                                                                                \
+            ++stage;                                                                                                    \
+        } while (0)
+
+        for (int l = 0; l < a.Ld; ++l) {
+            const PersistLayer<T>& W = a.L[l];
+            T* kc = a.skv + (size_t)(2 * l) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
+            T* vc = a.skv + (size_t)(2 * l + 1) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
+            {   // LN sandwich (or token + position embedding) + q,k,v projection; k,v appended to the cache (attention.py:124-127)
+                DecGemmArgs<T> g = gb; g.N = 3 * ID; g.K = D; g.W = W.wqkv; g.y = ly; g.x_out = lx;
+                g.tok = a.cur_tok + r0; g.tok_emb = a.tok_emb; g.pos_emb = a.pos_emb; g.q_out = lq; g.k_cache = kc; g.v_cache = vc;
+                if (l == 0) PS_GEMM(PRO_EMBED, EPI_QKV, ps_kw_pro<T>(D), 32, g, (3 * ID + 31) / 32);
+                else PS_GEMM(PRO_LN2, EPI_QKV, ps_kw_pro<T>(D), 32, g, (3 * ID + 31) / 32);
+            }
+            if (!placement_checked) {                         // every workgroup of the team has ORed its XCC id in by now
+                placement_checked = true;
+                ts();
+                if (threadIdx.x == 0) {
+                    const unsigned m = __hip_atomic_load(&ctl->xcc_mask[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_popcount(m) != 1) { atomicOr(&ctl->fail, 2u); *lds_dead = 1; }
+                }
+                __syncthreads();
+                ts.dead = ts.dead || *lds_dead != 0;
+            }
+            if (ts.dead) break;
+            DecAttnArgs<T> at{};
+            at.gamma = a.gamma; at.beta = a.beta; at.D = D; at.heads = HEADS; at.t_host = t; at.kv_div = 1; at.path = nullptr;
+            at.y = ly; at.x_out = lx; at.out = lao; at.qin = lq; at.tok = a.cur_tok + r0; at.tok_emb = a.tok_emb; at.pos_emb = a.pos_emb;
+            {   // causal self attention over the cache (attention.py:148-173, one query)
+                DecAttnArgs<T> s = at; s.W = W.wqkv; s.K = kc; s.V = vc; s.lmax = a.Tmax; s.len = 0;
+                PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s);
+            }
+            {   // gated output projection + residual (attention.py:96-99,180)
+                DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_s; g.bias = W.bo_s; g.A = lao; g.resid = lx; g.y_out = ly;
+                PS_GEMM(PRO_NONE, EPI_GLU_RES, ps_kw_half<T>(ID), 16, g, 2 * D / 16);
+            }
+            if (ts.dead) break;
+            {   // cross attention over the cached encoder projections, LN sandwich + q projection fused in front
+                DecAttnArgs<T> s = at; s.W = W.wq_c;
+                s.K = a.ckv + (size_t)(2 * l) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
+                s.V = a.ckv + (size_t)(2 * l + 1) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
+                s.lmax = a.N; s.len = a.N;
+                PS_ATTN(ATT_CROSS, APRO_LN2, 20, s);
+            }
+            {
+                DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_c; g.bias = W.bo_c; g.A = lao; g.resid = lx; g.y_out = ly;
+                PS_GEMM(PRO_NONE, EPI_GLU_RES, ps_kw_half<T>(ID), 16, g, 2 * D / 16);
+            }
+            if (ts.dead) break;
+            {   // GeGLU feed-forward (attention.py:9-17,41-67)
+                DecGemmArgs<T> g = gb; g.N = 2 * F; g.K = D; g.W = W.w1; g.bias = W.b1; g.y = ly; g.x_out = lx; g.h_out = lhid; g.F = F;
+                PS_GEMM(PRO_LN2, EPI_GEGLU, ps_kw_pro<T>(D), 32, g, 2 * F / 32);
+                DecGemmArgs<T> h = gb; h.N = D; h.K = F; h.W = W.w2; h.bias = W.b2; h.A = lhid; h.resid = lx; h.y_out = ly;
+                PS_GEMM(PRO_NONE, EPI_BIAS_RES, ps_kw_half<T>(F), 16, h, D / 16);
+            }
+            if (ts.dead) break;
+        }
+        if (ts.dead) break;
+        {   // final LayerNorm + logits of this position (decoder.py:57-60)
+            DecGemmArgs<T> g = gb; g.N = a.V; g.K = D; g.W = a.wlog; g.bias = a.blog; g.logits = llog; g.y = ly;
+            g.gamma = a.gamma_f; g.beta = a.beta_f;
+            PS_GEMM(PRO_LNF, EPI_LOGITS, ps_kw_pro<T>(D), 32, g, (a.V + 31) / 32);
+        }
+        {   // greedy token, append, eos bookkeeping (decoder.py:103-116): one wave per row, rows dealt over the team's waves
+            ts();
+            const int lane = threadIdx.x & 63, gw = rank * (PS_THREADS / 64) + (int)(threadIdx.x >> 6);
+            for (int r = gw; r < nr && !ts.dead; r += PS_TEAM_BLOCKS * (PS_THREADS / 64)) {
+                const int row = r0 + r;
+                const float* lg = a.dlogits + (size_t)row * a.V;
+                float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
+                float best = -3.4e38f; int bi = 0x7fffffff;
+                if ((a.V & 3) == 0) {
+                    const int n4 = a.V >> 2;
+                    for (int j4 = lane; j4 < n4; j4 += 64) {
+                        const float4 v = ldc_f4<true>(lg + j4 * 4);
+                        if (lo) reinterpret_cast<float4*>(lo)[j4] = v;
+                        const int j = j4 * 4;                   // ascending index: first maximum wins inside a lane
+                        if (v.x > best) { best = v.x; bi = j; }
+                        if (v.y > best) { best = v.y; bi = j + 1; }
+                        if (v.z > best) { best = v.z; bi = j + 2; }
+                        if (v.w > best) { best = v.w; bi = j + 3; }
+                    }
+                } else {
+                    for (int j = lane; j < a.V; j += 64) {
+                        const float v = ldc_f32<true>(lg + j);
+                        if (lo) lo[j] = v;
+                        if (v > best) { best = v; bi = j; }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }   // ties -> lowest index (torch.argmax)
+                }
+                if (lane == 0) {
+                    a.cur_tok[row] = bi;
+                    a.tokens_out[(size_t)row * a.out_stride + t] = bi;
+                    if (a.eos >= 0 && bi == a.eos &&
+                        __hip_atomic_load(reinterpret_cast<unsigned*>(a.eos_seen + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                        __hip_atomic_store(reinterpret_cast<unsigned*>(a.eos_seen + row), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicMax(&ctl->last_first_eos[team], t);
+                        __hip_atomic_fetch_add(&ctl->eos_rows[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (a.eos >= 0 && rank == 0 && threadIdx.x == 0) {
+                // rows counted up to the previous position are all visible here (they preceded a hand-off); this position's
+                // may or may not be -- the loop ends at most two positions late, and those positions are never returned
+                const unsigned n = __hip_atomic_load(&ctl->eos_rows[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n >= (unsigned)nr) {
+                    const unsigned bit = 1u << team;
+                    const unsigned old = atomicOr(&ctl->done_mask, bit);
+                    if (((old | bit) & full_mask) == full_mask)
+                        __hip_atomic_store(&ctl->stop[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            ts.arrive();
+            ++stage;
+        }
+        // the next position's first stage reads cur_tok; the stop word is read behind the same hand-off
+        ts();
+        if (ts.dead) break;
+        if (a.eos >= 0 && __hip_atomic_load(&ctl->stop[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ++t; break; }
+    }
+#undef PS_GEMM
+#undef PS_ATTN
+    if (rank == 0 && threadIdx.x == 0) ctl->steps_run[team] = t;
+}
+
+}  // namespace txo

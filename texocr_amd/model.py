@@ -47,11 +47,13 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _dev_f32(t: torch.Tensor, name: str) -> torch.Tensor:
+def _dev_f32(t: torch.Tensor, name: str, device: Optional[int] = None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError(f"{name} must be a CUDA/HIP tensor (this engine has no CPU path)")
     if t.dtype != torch.float32:
         raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if device is not None and t.device.index != device:
+        raise ValueError(f"{name} lives on cuda:{t.device.index} but the engine was created on cuda:{device}")
     return t.contiguous()
 
 
@@ -65,6 +67,9 @@ class HipEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the texocr_amd engine runs only on an MI355X (no CPU fallback)")
         self.dims, self.dtype = dims, dtype
+        # the engine's memory and streams belong to the device that is current NOW; every later call checks its
+        # tensors against it and runs with that device current
+        self.device = torch.cuda.current_device()
         self.max_batch, self.max_tokens = max_batch, max_tokens or dims.n_pos
         ch, cw = dims.canvas_hw
         cfg = _lib.TxoConfig(
@@ -112,19 +117,21 @@ class HipEngine:
     def encode(self, img: torch.Tensor) -> torch.Tensor:
         if img.ndim != 4:
             raise ValueError("expected an image batch of shape (B, C, H, W)")
-        img = _dev_f32(img, "src")
+        img = _dev_f32(img, "src", self.device)
         B, Cc, H, W = img.shape
         self.dims.check_image(Cc, H, W)
         out = torch.empty((B, self.dims.n_tokens(H, W), self.dims.embed_dim), device=img.device, dtype=torch.float32)
-        _lib.check(self.lib.txo_encode(self.handle, img.data_ptr(), B, Cc, H, W, out.data_ptr(), _stream()))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.txo_encode(self.handle, img.data_ptr(), B, Cc, H, W, out.data_ptr(), _stream()))
         return out
 
     def decode_begin(self, enc: torch.Tensor) -> None:
-        enc = _dev_f32(enc, "enc")
+        enc = _dev_f32(enc, "enc", self.device)
         if enc.ndim != 3 or enc.shape[2] != self.dims.embed_dim:
             raise ValueError(f"enc must be (B, N, {self.dims.embed_dim})")
         self._enc_keepalive = enc
-        _lib.check(self.lib.txo_decode_begin(self.handle, enc.data_ptr(), enc.shape[0], enc.shape[1], _stream()))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.txo_decode_begin(self.handle, enc.data_ptr(), enc.shape[0], enc.shape[1], _stream()))
         self._B = enc.shape[0]
 
     def decode_step(self, t: int, tok_in: Optional[torch.Tensor] = None, want_logits: bool = True):
@@ -135,16 +142,19 @@ class HipEngine:
         if tok_in is not None:
             if tok_in.dtype != torch.int64 or not tok_in.is_cuda or tok_in.shape != (B,):
                 raise ValueError("tok_in must be an int64 GPU tensor of shape (B,)")
+            if tok_in.device.index != self.device:
+                raise ValueError(f"tok_in lives on cuda:{tok_in.device.index} but the engine was created on cuda:{self.device}")
             tok_in = tok_in.contiguous()
-        _lib.check(self.lib.txo_decode_step(self.handle, tok_in.data_ptr() if tok_in is not None else None, int(t),
-                                            logits.data_ptr() if want_logits else None, nxt.data_ptr(), _stream()))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.txo_decode_step(self.handle, tok_in.data_ptr() if tok_in is not None else None, int(t),
+                                                logits.data_ptr() if want_logits else None, nxt.data_ptr(), _stream()))
         return logits, nxt
 
     def generate(self, img: Optional[torch.Tensor], max_len: int, eos: Optional[int], enc: Optional[torch.Tensor] = None,
                  return_logits: bool = False):
         if (img is None) == (enc is None):
             raise ValueError("pass exactly one of img / enc")
-        src = _dev_f32(img if img is not None else enc, "src" if img is not None else "enc")
+        src = _dev_f32(img if img is not None else enc, "src" if img is not None else "enc", self.device)
         B = src.shape[0]
         toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
         logits = torch.empty((B, max_len, self.dims.vocab), device=src.device, dtype=torch.float32) if return_logits else None
@@ -168,7 +178,7 @@ class HipEngine:
     def generate_beam(self, img: torch.Tensor, beams: int, max_len: int, eos: Optional[int], return_beams: bool = False):
         """Beam search (build extension; the reference has none).  Returns the best beam's tokens (B, n), or with
         return_beams=True (tokens (B, beams, n), scores (B, beams)) sorted best first."""
-        src = _dev_f32(img, "src")
+        src = _dev_f32(img, "src", self.device)
         B, Cc, H, W = src.shape
         self.dims.check_image(Cc, H, W)
         toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
@@ -187,6 +197,12 @@ class HipEngine:
         vocab 1000 because of float rounding -- then softmax(/temp) and one multinomial draw, decoder.py:104-108)."""
         k = int((1 - threshold) * self.dims.vocab)
         _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
+
+    def query(self, what: int) -> int:
+        """txo_engine_query: 0 = the last generate() ran as one persistent launch, 1 = persistent launches that fell back."""
+        out = C.c_int64(0)
+        _lib.check(self.lib.txo_engine_query(self.handle, int(what), C.byref(out)))
+        return out.value
 
     # profiling hooks used by bench.py
     def profile(self, on) -> None:
