@@ -577,16 +577,16 @@ def test_wide_decoder_large_batch_ffn_path():
 # the decode loop as ONE persistent launch (csrc/persist.h) against the launch-per-stage path
 # ------------------------------------------------------------------------------------------------
 def _both_paths(m, img, max_len, **kw):
-    """generate() through the persistent launch (default) and with TXO_PERSIST=0; asserts which path ran."""
+    """generate() through the persistent launch (opt-in: TXO_PERSIST=1) and through launches; asserts which path ran."""
     import os
-    out_p = m.generate(img, max_len, **kw)
-    assert m._engine.query(0) == 1, "the persistent launch did not run"
-    os.environ["TXO_PERSIST"] = "0"
+    os.environ["TXO_PERSIST"] = "1"
     try:
-        out_l = m.generate(img, max_len, **kw)
-        assert m._engine.query(0) == 0
+        out_p = m.generate(img, max_len, **kw)
+        assert m._engine.query(0) == 1, "the persistent launch did not run"
     finally:
         os.environ.pop("TXO_PERSIST")
+    out_l = m.generate(img, max_len, **kw)
+    assert m._engine.query(0) == 0
     assert m._engine.query(1) == 0, "a persistent launch fell back to launches"
     return out_p, out_l
 
@@ -614,8 +614,11 @@ def test_persistent_decode_global_eos_break():
     d, sd, m = build(d, seed=11, max_batch=20)
     img = torch.from_numpy(synth.synth_images(20, 3, 32, 96, seed=5)).cuda()
     # pick as eos a token that every row emits, the last row as late as possible (rows and teams finish at different positions)
+    import os
+    os.environ["TXO_PERSIST"] = "1"
     m.eos_token = None
     free = m.generate(img, 256).cpu().numpy()
+    os.environ.pop("TXO_PERSIST")
     best = None
     for tok in range(d.vocab):
         hit = free == tok
@@ -636,7 +639,11 @@ def test_persistent_decode_global_eos_break():
     assert bool((tp == eos).any(dim=1).all()) and not bool((tp[:, :-1] == eos).any(dim=1).all())
     # eos_tok = None: never breaks
     m.eos_token = None
-    assert m.generate(img, 48).shape == (20, 48) and m._engine.query(0) == 1
+    os.environ["TXO_PERSIST"] = "1"
+    try:
+        assert m.generate(img, 48).shape == (20, 48) and m._engine.query(0) == 1
+    finally:
+        os.environ.pop("TXO_PERSIST")
     # bos == eos: the BOS column already satisfies the test -> one step (decoder.py:115 looks at the whole output)
     d2 = Dims(canvas=224, vocab=16, bos=5, eos=5, pad=15, max_len=64)
     d2, sd2, m2 = build(d2, seed=11, max_batch=20)

@@ -108,9 +108,10 @@ template <bool BEAM> struct DecAttnLds {
 // the K panel does not depend on the previous stage (cross attention), so every wave except the one that polls the team
 // counter (tid < 64 of the workgroup's first group: a poll's wait would also wait for that wave's own panel) requests it
 // BEFORE the wait.  valid = false: same barriers, clamped addresses, no stores.
-template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM, bool COH, class Wait>
+// pf(): called once this tile's own loads have been issued (persistent kernel: requests the next stage's weights there).
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM, bool COH, class Wait, class Pf = NoPf>
 __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, int tid, DecAttnLds<BEAM>& L_, bool valid,
-                                              bool poll_wave, Wait&& wait_prev) {
+                                              bool poll_wave, Wait&& wait_prev, Pf&& pf = NoPf{}) {
     constexpr int PER16 = Elem<T>::PER16;
     constexpr int LPR = DH / PER16;          // lanes per 64-element row: 16 (f32) / 8 (bf16)
     constexpr int KPI = 64 / LPR;            // keys per wave-instruction: 4 / 8
@@ -152,9 +153,14 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
 
     // ---- 1. request the K panel of the first pass ----
     constexpr bool KV_EARLY = COH && MODE == ATT_CROSS && !BEAM;   // persistent kernel: the cross panel is older than the launch
-    if constexpr (!KV_EARLY) wait_prev();
+    // persistent kernel, plain self attention: rows 0..t-1 of the cache are older than this position's hand-offs, so the
+    // history is requested BEFORE the wait; only row t (appended by the stage before this one) is read behind it and takes
+    // the place of its key by selects (same values in the same operations -> same bits).  A row is never requested before
+    // its own position's hand-off (an early copy in this CU's L1 would outlive the append), hence nothing is early at t = 0.
+    constexpr bool HIST_EARLY = COH && MODE == ATT_SELF && !FUSED && !BEAM;
+    if constexpr (!KV_EARLY && !HIST_EARLY) wait_prev();
     int t = 0;
-    if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
+    if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = (COH || a.t_host >= 0) ? a.t_host : *a.t_ptr;
     // cached keys: fused self handles the new key t apart; plain self finds it in the cache already
     const int L = MODE == ATT_CROSS ? a.len : (FUSED ? t : t + 1);
     const int Lm1 = max(L - 1, 0);
@@ -176,19 +182,38 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     // cache policy: the cross panels (309 MB per step at batch 64) are streamed non-temporally so that they do not push
     // the decoder weights out of L2; the self-attention history (<= 67 MB over all layers) is re-read every step and
     // is read with the default policy (measured: self-attention launch 6.2 -> 5.4 us)
-    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF) return ldc16<COH>(p); else return ld16_stream(p); };
+    // the self-attention cache is read with plain loads also in the persistent kernel: a row is final once its position's
+    // hand-off has passed, and no CU reads it earlier (clamps below), so no L1 can hold an older copy of its lines
+    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF) return ld16(p); else return ld16_stream(p); };
+    int clamp_row = Lm1;
     auto issue_k = [&](int base) {
 #pragma unroll
-        for (int u = 0; u < NL; ++u) rk[u] = ld_kv(Kb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
+        for (int u = 0; u < NL; ++u) rk[u] = ld_kv(Kb + row_off(min(base + u * KPB + key0, clamp_row)) + sub * PER16);
         if constexpr (V_EARLY) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u) rv[u] = ld_kv(Vb + row_off(min(base + u * KPB + key0, Lm1)) + sub * PER16);
+            for (int u = 0; u < NL; ++u) rv[u] = ld_kv(Vb + row_off(min(base + u * KPB + key0, clamp_row)) + sub * PER16);
         }
     };
+    [[maybe_unused]] u32x4 kt = {0u, 0u, 0u, 0u}, vt = {0u, 0u, 0u, 0u};
     if constexpr (KV_EARLY) {
         if (!poll_wave) issue_k(0);
         wait_prev();
         if (poll_wave) issue_k(0);
+    } else if constexpr (HIST_EARLY) {
+        const bool early = t > 0 && !poll_wave;                // the polling wave's wait would wait for its own panel too
+        clamp_row = max(t - 1, 0);
+        if (early) issue_k(0);
+        wait_prev();
+        if (!early) {
+            if (t > 0) issue_k(0);
+            else {
+#pragma unroll
+                for (int u = 0; u < NL; ++u) { rk[u] = kt; rv[u] = kt; }   // t = 0: no history; zeros (finite) under masked keys
+            }
+        }
+        kt = ld16(Kb + (size_t)t * DH + sub * PER16);
+        vt = ld16(Vb + (size_t)t * DH + sub * PER16);
+        clamp_row = Lm1;                                       // later passes of a long history run behind the wait anyway
     } else {
         issue_k(0);
     }
@@ -313,6 +338,8 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     for (int e = 0; e < PER16; ++e)
         qv[e] = (FUSED ? qkv[0][sub * PER16 + e] : ldc_f32<COH>(a.qin + (size_t)img * inner + head * DH + sub * PER16 + e)) * ATTN_SCALE;
 
+    pf();
+
     // ---- 4. passes over the panel (one pass when len <= NL*KPB) ----
     float m_run = (MODE == ATT_SELF && FUSED) ? s_new : -3.0e38f, l_run = 0.f;
     float acc[PER16];
@@ -326,7 +353,14 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         for (int u = 0; u < NL; ++u) {
             const int key = base + u * KPB + key0;
             float kf[PER16];
-            unpack16<T, PER16>(rk[u], kf);
+            if constexpr (HIST_EARLY) {
+                const bool is_t = key == t;
+                u32x4 kk = rk[u];
+                kk.x = is_t ? kt.x : kk.x; kk.y = is_t ? kt.y : kk.y; kk.z = is_t ? kt.z : kk.z; kk.w = is_t ? kt.w : kk.w;
+                unpack16<T, PER16>(kk, kf);
+            } else {
+                unpack16<T, PER16>(rk[u], kf);
+            }
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
@@ -355,7 +389,14 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
             const float p = expf(sc[u] - m_new);              // masked keys: exp(-3e38 - m) == 0 exactly
             l_run = fmaf(p, count_me, l_run);
             float vf[PER16];
-            unpack16<T, PER16>(rv[u], vf);
+            if constexpr (HIST_EARLY) {
+                const bool is_t = base + u * KPB + key0 == t;
+                u32x4 vv = rv[u];
+                vv.x = is_t ? vt.x : vv.x; vv.y = is_t ? vt.y : vv.y; vv.z = is_t ? vt.z : vv.z; vv.w = is_t ? vt.w : vv.w;
+                unpack16<T, PER16>(vv, vf);
+            } else {
+                unpack16<T, PER16>(rv[u], vf);
+            }
 #pragma unroll
             for (int e = 0; e < PER16; ++e) acc[e] = fmaf(p, vf[e], acc[e]);
         }

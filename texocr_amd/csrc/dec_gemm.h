@@ -60,6 +60,15 @@ template <bool COH> __device__ inline float4 ldc_f4(const float* p) {
 // kernel (the launch boundary is the dependency); the persistent kernel waits for its team's arrival counter here
 struct NoWait { __device__ inline void operator()() const {} };
 
+struct NoPf { __device__ inline void operator()() const {} };
+
+// Weight fragments of one tile (one wave's share, K fixed at compile time: KW 64-byte chunks per wave) can be requested one
+// stage ahead by the persistent kernel (dec_gemm_prefetch) into ONE small register buffer shared by all stages:
+// layout w0[0..KW) then (32-column tiles) w1[0..KW).
+constexpr int wfrag_regs(int KW, int BN) { return KW * (BN == 32 ? 2 : 1); }
+constexpr int WBUF_REGS = 8;
+struct WBuf { u32x4 r[WBUF_REGS]; };
+
 template <typename T> struct DecGemmArgs {
     // problem
     int rows, N, K;                 // rows = batch, W is [N][K]
@@ -122,9 +131,30 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
 // One output tile (rows by*16.., columns bx*BN..) by 256 threads (tid 0..255; in the persistent kernel two such groups share
 // a 512-thread workgroup, each with its own `smem`).  valid = false: the group has no tile in this round -- it runs the same
 // barriers on clamped addresses and stores nothing.
-template <typename T, int PRO, int EPI, int KW, int BN, bool COH, class Wait>
-__device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem, bool valid,
-                                              Wait&& wait_prev) {
+template <typename T, int KW, int BN>
+__device__ __forceinline__ void dec_gemm_prefetch(WBuf& f, const T* W, int N, int bx, int tid, bool real) {
+    static_assert(KW > 0, "compile-time K only");
+    constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK, K = KW * 4 * KCH;
+    static_assert(wfrag_regs(KW, BN) <= WBUF_REGS, "prefetch buffer too small");
+    // no branch around the loads (a conditional load makes hipcc's later waits vmcnt(0)): a group without a tile in that
+    // stage re-reads the first rows of W, which its neighbours keep hot in L2
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    const int n0 = real ? bx * BN : 0;
+    const T* w0 = W + (size_t)min(n0 + lr, N - 1) * K + lg * PER16;
+    const T* w1 = W + (size_t)min(n0 + 16 + lr, N - 1) * K + lg * PER16;
+#pragma unroll
+    for (int c = 0; c < KW; ++c) {
+        f.r[c] = ld16(w0 + (wave + 4 * c) * KCH);
+        if constexpr (BN == 32) f.r[KW + c] = ld16(w1 + (wave + 4 * c) * KCH);
+    }
+}
+
+// pre: the tile's weight fragments if they were requested earlier (persistent kernel), else null; pf(): called once the
+// tile's own activation loads have been issued -- the persistent kernel requests the NEXT stage's weights there (vector
+// memory returns in order, so anything requested before the activations would delay them)
+template <typename T, int PRO, int EPI, int KW, int BN, bool COH, bool HASPRE, class Wait, class Pf>
+__device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem, bool valid,
+                                                 Wait&& wait_prev, const WBuf& pre, Pf&& pf) {
     // value/gate-paired epilogues (GLU, GeGLU) run on ONE 16-column tile whose weight rows are interleaved by 8
     // (8 value rows, then their 8 gate rows): lane lr < 8 holds the value, lane lr + 8 the gate of output n0/2 + lr
     constexpr bool PAIRED = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
@@ -181,7 +211,23 @@ __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, i
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
             fa[c] = ldc16<COH>(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
     };
-    load_w(0);
+    if constexpr (HASPRE) {
+        static_assert(FIXED && wfrag_regs(KW, BN) <= WBUF_REGS, "prefetched fragments need a compile-time K that fits the buffer");
+#pragma unroll
+        for (int c = 0; c < GROUP; ++c) { fw0[c] = pre.r[c]; if constexpr (TWO) fw1[c] = pre.r[(KW + c) % WBUF_REGS]; }
+    } else {
+        load_w(0);
+    }
+    // LayerNorm affine of the prologue: static as well
+    [[maybe_unused]] float4 lng[NVMAX], lnb[NVMAX];
+    if constexpr (PRO != PRO_NONE) {
+        const int sub = tid & 15, nv = FIXED ? NVMAX : K >> 6;
+#pragma unroll
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) {
+            lng[i] = *reinterpret_cast<const float4*>(a.gamma + i * 64 + sub * 4);
+            lnb[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
+        }
+    }
     // everything above is weights / biases; everything below reads what the previous stage produced
     wait_prev();
     if constexpr (EPI == EPI_GLU_RES) {
@@ -192,7 +238,7 @@ __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, i
     }
     int t = 0;
     if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
-    if constexpr (PRO == PRO_NONE) load_a_global(0);
+    if constexpr (PRO == PRO_NONE) { load_a_global(0); pf(); }
     // keep every fragment load ahead of the first MFMA: with K fixed this is one basic block and the machine
     // scheduler would otherwise interleave loads and MFMAs four at a time (serialising the memory latency)
     __builtin_amdgcn_sched_barrier(0);
@@ -202,12 +248,8 @@ __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, i
         const int sub = tid & 15, r = tid >> 4, nv = FIXED ? NVMAX : K >> 6;
         const float inv_d = 1.0f / K;
         const int m = min(m0 + r, rows - 1);
-        float4 v[NVMAX], g[NVMAX], b[NVMAX];
-#pragma unroll
-        for (int i = 0; i < NVMAX; ++i) if (i < nv) {
-            g[i] = *reinterpret_cast<const float4*>(a.gamma + i * 64 + sub * 4);
-            b[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
-        }
+        float4 v[NVMAX];
+        float4 (&g)[NVMAX] = lng; float4 (&b)[NVMAX] = lnb;
         if constexpr (PRO == PRO_EMBED) {
             const float* te = a.tok_emb + (size_t)ldc_i64<COH>(a.tok + m) * K;
             const float* pe = a.pos_emb + (size_t)t * K;
@@ -222,6 +264,7 @@ __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, i
             for (int i = 0; i < NVMAX; ++i) if (i < nv)
                 v[i] = ldc_f4<COH>(a.y + (size_t)m * K + i * 64 + sub * 4);
         }
+        pf();
         if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, g, b, inv_d);
         if constexpr (PRO == PRO_EMBED || PRO == PRO_LN2) {
             if (bx == 0 && valid && m0 + r < rows) {
@@ -308,6 +351,13 @@ __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, i
             }
         }
     }
+}
+
+template <typename T, int PRO, int EPI, int KW, int BN, bool COH, class Wait>
+__device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem, bool valid,
+                                              Wait&& wait_prev) {
+    const WBuf none{};
+    dec_gemm_tile_pf<T, PRO, EPI, KW, BN, COH, false>(a, bx, by, tid, smem, valid, wait_prev, none, NoPf{});
 }
 
 template <typename T, int PRO, int EPI, int KW, int BN = DG_BN>

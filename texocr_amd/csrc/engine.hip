@@ -892,7 +892,11 @@ struct Engine : EngineBase {
 
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
     bool persist_usable() const {
-        if (const char* e = getenv("TXO_PERSIST")) { if (atoi(e) == 0) return false; }
+        // opt-in (TXO_PERSIST=1): measured on MI355X at batch 64 the persistent launch needs 181 us per position against
+        // 173 us for the 30 launches (profiles/r02_persist_*_stamps.txt: a hand-off costs ~1.5-2 us and the stage bodies are
+        // no shorter than the launched kernels'), so launches stay the default
+        const char* pe = getenv("TXO_PERSIST");
+        if (!pe || atoi(pe) == 0) return false;
         if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         if (D == 256 && cfg.dec_heads == 8) return true;
@@ -927,6 +931,7 @@ struct Engine : EngineBase {
         pa.ctl = pctl; pa.stamps = pstamps;
         const char* stamp_file = getenv("TXO_PSTAMPS");
         pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
+        if (const char* sg = getenv("TXO_PS_STAGGER_US")) pa.stagger_ticks = (int)(atof(sg) * 100.0);
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
         if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));
         if (D == 256) { if (int r = launch_persist<256, 8>(pa, s)) return r; }

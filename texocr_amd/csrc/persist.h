@@ -67,6 +67,7 @@ template <typename T> struct PersistArgs {
     T *skv, *ckv; size_t self_stride, cross_stride;           // per (layer, k|v) plane
     int64_t* tokens_out; int out_stride; float* logits_out;
     PersistCtl* ctl;
+    int stagger_ticks;                                        // experiment: team k starts k * this many 10-ns ticks late (desynchronises the teams' HBM phases)
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
 };
 
@@ -152,6 +153,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             __hip_atomic_store(&ctl->eos_rows[team], (unsigned)nr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (a.stagger_ticks > 0 && team > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), until = (unsigned long long)a.stagger_ticks * team;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < until) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
     TeamSync ts{&ctl->counter[team][0], 0u, &ctl->fail, lds_dead, false, false, nullptr};
     bool placement_checked = false;
@@ -165,51 +170,83 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     unsigned long long* stamp_base = (a.stamps && srank >= 0 && threadIdx.x == 0)
         ? a.stamps + ((size_t)team * PS_STAMP_RANKS + srank) * PS_MAX_STAGES * PS_STAMP_WORDS : nullptr;
 
+    // the tile column this group takes in round 0 of a GEMM stage with `ncol` column tiles (what PS_GEMM computes)
+    auto bx0 = [&](int ncol) { const int nt = ncol * nrt; return (sb < nt ? sb : nt - 1) % ncol; };
+    auto has0 = [&](int ncol) { return rank * 2 < ncol * nrt; };        // this workgroup runs a tile in round 0
+    constexpr int KWP = ps_kw_pro<T>(D), KWI = ps_kw_half<T>(ID), KWF = ps_kw_half<T>(F);
+    constexpr int NC_QKV = (3 * ID + 31) / 32, NC_O = 2 * D / 16, NC_F1 = 2 * F / 32, NC_F2 = D / 16;
+    const int nc_log = (a.V + 31) / 32;
+    // ONE register buffer for the weight fragments requested a stage ahead (<= 8 x 16 bytes per lane; stages whose tile needs
+    // more request their weights themselves, as the launch path does)
+    // PS_AHEAD: request a stage's weights one stage ahead into `wbuf`.  Measured (profiles/r02_persist_*): the 32 extra live
+    // registers push the attention stages (already at the 256-VGPR limit of an 8-wave workgroup) into scratch, and the
+    // arrival's vmcnt(0) drain waits for the early request anyway (vector memory returns in order) -- slower, so off.
+    constexpr bool PS_AHEAD = false;
+    constexpr bool PF_P = PS_AHEAD && KWP > 0 && wfrag_regs(KWP, 32) <= WBUF_REGS, PF_I = PS_AHEAD && KWI > 0 && wfrag_regs(KWI, 16) <= WBUF_REGS,
+                   PF_F = PS_AHEAD && KWF > 0 && wfrag_regs(KWF, 16) <= WBUF_REGS;
+    WBuf wbuf;
+    if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
+
     int t = 0;
     for (; t < a.max_len; ++t) {
         gb.t_host = t;
         int stage = 0;
         ts.stp = (stamp_base && t == a.stamp_step) ? stamp_base : nullptr;
-        // one GEMM stage: tiles (bx, by) dealt over the team's groups; a workgroup with no tile only synchronises
-#define PS_GEMM(PRO, EPI, KW, BN, ARGS, NCOL)                                                                           \
+        // one GEMM stage: tiles (bx, by) dealt over the team's groups; a workgroup with no tile only synchronises.
+        // PRE: the first round's weight fragments when an earlier stage requested them (else nullptr); PF: what this stage
+        // requests for a later one once its own loads are out
+#define PS_GEMM(PRO, EPI, KW, BN, ARGS, NCOL, PRE, PF)                                                                  \
         do {                                                                                                            \
             const int ncol_ = (NCOL), nt_ = ncol_ * nrt;                                                                \
             for (int base_ = 0; base_ < nt_; base_ += NSB) {                                                            \
                 if (base_ > 0) __syncthreads();          /* the previous round's LDS reads are done */                  \
                 if (base_ + rank * 2 < nt_) {                                                                           \
                     const int tile_ = base_ + sb; const bool ok_ = tile_ < nt_; const int tc_ = ok_ ? tile_ : nt_ - 1;  \
-                    dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts);       \
-                }                                                                                                       \
+                    if (base_ == 0) dec_gemm_tile_pf<T, PRO, EPI, KW, BN, true, PRE>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts, wbuf, PF); \
+                    else dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts);  \
+                } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
             ts();                                                                                                       \
             ts.arrive();                                                                                                \
             ++stage;                                                                                                    \
         } while (0)
-#define PS_ATTN(MODE, APRO, NLV, ARGS)                                                                                  \
+#define PS_ATTN(MODE, APRO, NLV, ARGS, PF)                                                                              \
         do {                                                                                                            \
             const int np_ = nr * HEADS;                                                                                 \
             for (int base_ = 0; base_ < np_; base_ += NSB) {                                                            \
                 if (base_ > 0) __syncthreads();                                                                         \
                 if (base_ + rank * 2 < np_) {                                                                           \
                     const int p_ = base_ + sb; const bool ok_ = p_ < np_;                                               \
-                    dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid,             \
+                    if (base_ == 0) dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid, \
+                        *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts, PF);                           \
+                    else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid,        \
                         *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts);                               \
-                }                                                                                                       \
+                } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
             ts();                                                                                                       \
             ts.arrive();                                                                                                \
             ++stage;                                                                                                    \
         } while (0)
-
         for (int l = 0; l < a.Ld; ++l) {
             const PersistLayer<T>& W = a.L[l];
             T* kc = a.skv + (size_t)(2 * l) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
             T* vc = a.skv + (size_t)(2 * l + 1) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
+            auto pf_os = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_s, 2 * D, bx0(NC_O), tid, has0(NC_O)); };
+            auto pf_oc = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_c, 2 * D, bx0(NC_O), tid, has0(NC_O)); };
+            auto pf_f1 = [&]() { if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, W.w1, 2 * F, bx0(NC_F1), tid, has0(NC_F1)); };
+            auto pf_f2 = [&]() { if constexpr (PF_F) dec_gemm_prefetch<T, KWF, 16>(wbuf, W.w2, D, bx0(NC_F2), tid, has0(NC_F2)); };
+            auto pf_next = [&]() {                            // behind the layer's last stage: next layer's q,k,v or the logits
+                if constexpr (PF_P) {
+                    if (l + 1 < a.Ld) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[l + 1].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
+                    else dec_gemm_prefetch<T, KWP, 32>(wbuf, a.wlog, a.V, bx0(nc_log), tid, has0(nc_log));
+                }
+            };
+            auto none = []() {};
             {   // LN sandwich (or token + position embedding) + q,k,v projection; k,v appended to the cache (attention.py:124-127)
                 DecGemmArgs<T> g = gb; g.N = 3 * ID; g.K = D; g.W = W.wqkv; g.y = ly; g.x_out = lx;
                 g.tok = a.cur_tok + r0; g.tok_emb = a.tok_emb; g.pos_emb = a.pos_emb; g.q_out = lq; g.k_cache = kc; g.v_cache = vc;
-                if (l == 0) PS_GEMM(PRO_EMBED, EPI_QKV, ps_kw_pro<T>(D), 32, g, (3 * ID + 31) / 32);
-                else PS_GEMM(PRO_LN2, EPI_QKV, ps_kw_pro<T>(D), 32, g, (3 * ID + 31) / 32);
+                if (l == 0) PS_GEMM(PRO_EMBED, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
+                else PS_GEMM(PRO_LN2, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
             }
             if (!placement_checked) {                         // every workgroup of the team has ORed its XCC id in by now
                 placement_checked = true;
@@ -227,11 +264,11 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             at.y = ly; at.x_out = lx; at.out = lao; at.qin = lq; at.tok = a.cur_tok + r0; at.tok_emb = a.tok_emb; at.pos_emb = a.pos_emb;
             {   // causal self attention over the cache (attention.py:148-173, one query)
                 DecAttnArgs<T> s = at; s.W = W.wqkv; s.K = kc; s.V = vc; s.lmax = a.Tmax; s.len = 0;
-                PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s);
+                PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s, pf_os);
             }
             {   // gated output projection + residual (attention.py:96-99,180)
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_s; g.bias = W.bo_s; g.A = lao; g.resid = lx; g.y_out = ly;
-                PS_GEMM(PRO_NONE, EPI_GLU_RES, ps_kw_half<T>(ID), 16, g, 2 * D / 16);
+                PS_GEMM(PRO_NONE, EPI_GLU_RES, KWI, 16, g, NC_O, PF_I, none);
             }
             if (ts.dead) break;
             {   // cross attention over the cached encoder projections, LN sandwich + q projection fused in front
@@ -239,45 +276,58 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 s.K = a.ckv + (size_t)(2 * l) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.V = a.ckv + (size_t)(2 * l + 1) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.lmax = a.N; s.len = a.N;
-                PS_ATTN(ATT_CROSS, APRO_LN2, 20, s);
+                PS_ATTN(ATT_CROSS, APRO_LN2, 20, s, pf_oc);
             }
             {
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_c; g.bias = W.bo_c; g.A = lao; g.resid = lx; g.y_out = ly;
-                PS_GEMM(PRO_NONE, EPI_GLU_RES, ps_kw_half<T>(ID), 16, g, 2 * D / 16);
+                PS_GEMM(PRO_NONE, EPI_GLU_RES, KWI, 16, g, NC_O, PF_I, pf_f1);
             }
             if (ts.dead) break;
             {   // GeGLU feed-forward (attention.py:9-17,41-67)
                 DecGemmArgs<T> g = gb; g.N = 2 * F; g.K = D; g.W = W.w1; g.bias = W.b1; g.y = ly; g.x_out = lx; g.h_out = lhid; g.F = F;
-                PS_GEMM(PRO_LN2, EPI_GEGLU, ps_kw_pro<T>(D), 32, g, 2 * F / 32);
+                PS_GEMM(PRO_LN2, EPI_GEGLU, KWP, 32, g, NC_F1, PF_P, pf_f2);
                 DecGemmArgs<T> h = gb; h.N = D; h.K = F; h.W = W.w2; h.bias = W.b2; h.A = lhid; h.resid = lx; h.y_out = ly;
-                PS_GEMM(PRO_NONE, EPI_BIAS_RES, ps_kw_half<T>(F), 16, h, D / 16);
+                PS_GEMM(PRO_NONE, EPI_BIAS_RES, KWF, 16, h, NC_F2, PF_F, pf_next);
             }
             if (ts.dead) break;
         }
         if (ts.dead) break;
+        auto pf_step = [&]() {                                // behind the logits: the next position's first q,k,v projection
+            if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
+        };
         {   // final LayerNorm + logits of this position (decoder.py:57-60)
             DecGemmArgs<T> g = gb; g.N = a.V; g.K = D; g.W = a.wlog; g.bias = a.blog; g.logits = llog; g.y = ly;
             g.gamma = a.gamma_f; g.beta = a.beta_f;
-            PS_GEMM(PRO_LNF, EPI_LOGITS, ps_kw_pro<T>(D), 32, g, (a.V + 31) / 32);
+            PS_GEMM(PRO_LNF, EPI_LOGITS, KWP, 32, g, nc_log, PF_P, pf_step);
         }
-        {   // greedy token, append, eos bookkeeping (decoder.py:103-116): one wave per row, rows dealt over the team's waves
+        {   // greedy token, append, eos bookkeeping (decoder.py:103-116): one wave per row, rows dealt over the team's workgroups
             ts();
-            const int lane = threadIdx.x & 63, gw = rank * (PS_THREADS / 64) + (int)(threadIdx.x >> 6);
-            for (int r = gw; r < nr && !ts.dead; r += PS_TEAM_BLOCKS * (PS_THREADS / 64)) {
+            const int lane = threadIdx.x & 63;
+            for (int r = (int)(threadIdx.x >> 6) * PS_TEAM_BLOCKS + rank; r < nr && !ts.dead; r += PS_TEAM_BLOCKS * (PS_THREADS / 64)) {
                 const int row = r0 + r;
                 const float* lg = a.dlogits + (size_t)row * a.V;
                 float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
                 float best = -3.4e38f; int bi = 0x7fffffff;
-                if ((a.V & 3) == 0) {
+                if ((a.V & 3) == 0) {                          // four 16-byte pieces per lane in flight
                     const int n4 = a.V >> 2;
-                    for (int j4 = lane; j4 < n4; j4 += 64) {
-                        const float4 v = ldc_f4<true>(lg + j4 * 4);
-                        if (lo) reinterpret_cast<float4*>(lo)[j4] = v;
-                        const int j = j4 * 4;                   // ascending index: first maximum wins inside a lane
-                        if (v.x > best) { best = v.x; bi = j; }
-                        if (v.y > best) { best = v.y; bi = j + 1; }
-                        if (v.z > best) { best = v.z; bi = j + 2; }
-                        if (v.w > best) { best = v.w; bi = j + 3; }
+                    for (int base = 0; base < n4; base += 256) {
+                        float4 v[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j4 = base + u * 64 + lane;
+                            v[u] = ldc_f4<true>(lg + min(j4, n4 - 1) * 4);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j4 = base + u * 64 + lane;
+                            if (j4 >= n4) continue;
+                            if (lo) reinterpret_cast<float4*>(lo)[j4] = v[u];
+                            const int j = j4 * 4;               // ascending index: first maximum wins inside a lane
+                            if (v[u].x > best) { best = v[u].x; bi = j; }
+                            if (v[u].y > best) { best = v[u].y; bi = j + 1; }
+                            if (v[u].z > best) { best = v[u].z; bi = j + 2; }
+                            if (v[u].w > best) { best = v[u].w; bi = j + 3; }
+                        }
                     }
                 } else {
                     for (int j = lane; j < a.V; j += 64) {
