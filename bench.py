@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: images/sec of OCRModel.generate() on synthetic 3x224x672 batches, greedy,
-max_len=256 (BASELINE.json configs[1]: config.yml dims, batch 64 per GPU).
+max_len=256 (BASELINE.json configs[1]: config.yml dims, batch 64 per GPU, bf16 as that config names).
 
 A "step" is one generate() call over one batch: ViT patch-embed + encoder stack, cross-K/V projection,
-256 KV-cached decode steps, and (N>1) the RCCL all-gather of the token ids.  Inputs are resident in HBM
-before the timed region.  One process per GPU (the driver launches torch.distributed.run for N>1); rank 0
-prints ONE JSON line.
+256 KV-cached decode steps, and (under torch.distributed) the RCCL all-gather of the token ids.  Inputs are
+resident in HBM before the timed region.  One process per GPU (the driver launches torch.distributed.run for
+N>1); rank 0 prints ONE JSON line.
 
-Extra objects on the line:
+Objects on the line besides the contract's fields:
   roofline     -- decode-step cross-attention kernel (the HBM-bound kernel north_star names): algorithmic
                   bytes per launch = B*heads*2*N*64*sizeof(dtype), divided by the kernel's average launch
-                  duration measured with HIP events on the engine's stream in a separate profiled pass
-                  (event pairs around each launch; not part of the timed region).
-  cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") in recompute mode = the reference's algorithm
-                  (no KV cache), timed on this host on a bounded sample of the same workload.
+                  duration measured with HIP events bound to the dispatches of the LAST timed step.
+                  `traffic` = PMC bytes per launch from a separate rocprofv3 pass (file named in `traffic_source`).
+  cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") on this host: `value` = recompute mode = the reference's
+                  algorithm (no KV cache, decoder.py:97-103) on a bounded sample; `cached` = the same oracle with a KV cache.
+  fp32_parity_mode, b256, cfg4 (N=1 only, after the timed region; --no-extras skips them):
+                  the token-exact fp32 engine on the same workload; batch 256 (the north-star HBM target: cross-attention
+                  >= 50 % of 8 TB/s); BASELINE configs[3] (ViT-Base 12L/768d + 6L decoder, B=256: encoder >= 40 % of the
+                  bf16 MFMA peak).
 """
 from __future__ import annotations
 
@@ -42,26 +46,107 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("TEXOCR_BENCH_DTYPE", "bf16"), choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / batch-256 / config-4 side measurements")
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--cpu-budget-seconds", type=float, default=40.0)
     return ap.parse_args()
 
 
 def cpu_baseline(dims, sd_np, a):
-    """Reference algorithm (full-prefix recompute, cross K/V re-projected every step) on the host CPU."""
+    """Reference algorithm (full-prefix recompute, cross K/V re-projected every step) on the host CPU, plus the oracle's
+    KV-cached form.  Bounded: the recompute sample is `--cpu-sample-batch` images; if a first short probe says the full 256
+    steps would not fit the budget the batch is halved (the sample is stated in the output)."""
     import torch
     from oracle import cpu_ref
     from texocr_amd import synth
-    b = a.cpu_sample_batch
-    img = torch.from_numpy(synth.synth_images(b, dims.in_channels, a.height, a.width, seed=1234))
     sd = cpu_ref.to_torch_sd(sd_np)
-    cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, 4)            # warm the thread pool
+    b = a.cpu_sample_batch
+    while True:
+        img = torch.from_numpy(synth.synth_images(b, dims.in_channels, a.height, a.width, seed=1234))
+        cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, 2)              # warm the thread pool
+        t0 = time.perf_counter()
+        cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, 24)
+        probe = time.perf_counter() - t0
+        # recompute cost per step grows linearly with the prefix: sum_{t<=T} t ~ T^2/2
+        est = probe * (a.max_len * (a.max_len + 1)) / (24 * 25)
+        if est <= a.cpu_budget_seconds or b <= 2:
+            break
+        b //= 2
     t0 = time.perf_counter()
     toks = cpu_ref.generate_recompute(sd, img, dims.bos, dims.eos, a.max_len)
     dt = time.perf_counter() - t0
     assert toks.shape[1] == a.max_len
+    bc = 64
+    imgc = torch.from_numpy(synth.synth_images(bc, dims.in_channels, a.height, a.width, seed=1234))
+    t0 = time.perf_counter()
+    tc = cpu_ref.generate_cached(sd, imgc, dims.bos, dims.eos, a.max_len)
+    dtc = time.perf_counter() - t0
+    assert tc.shape[1] == a.max_len
     return {"value": round(b / dt, 4), "unit": "images/sec", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"oracle recompute mode (reference algorithm, no KV cache), {b} images {dims.in_channels}x{a.height}x{a.width}, "
-                      f"{a.max_len} greedy steps, {dt:.1f} s wall, torch CPU fp32"}
+                      f"{a.max_len} greedy steps, {dt:.1f} s wall, torch CPU fp32",
+            "cached": {"value": round(bc / dtc, 3), "unit": "images/sec",
+                       "sample": f"oracle KV-cached mode, {bc} images, {a.max_len} steps, {dtc:.1f} s wall"}}
+
+
+def timed(model, img, max_len, warm, steps):
+    import torch
+    for _ in range(warm):
+        model.generate(img, max_len)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model.generate(img, max_len)
+    torch.cuda.synchronize()
+    assert out.shape[1] == max_len
+    return (time.perf_counter() - t0) / steps
+
+
+def enc_flop(dims, B, N):
+    """encoder (patch-embed + ViT stack) FLOPs, SURVEY 8d: 2(N-1)C*256*D + Le*(N(10DI + 6DF) + 4N^2 I) per image"""
+    D_, I_, F_, Le = dims.embed_dim, dims.enc_inner, dims.enc_ffn, dims.enc_layers
+    return B * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
+
+
+def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encoder):
+    """One extra configuration on this GPU: throughput, and on request the cross-attention launch (HIP events bound to the
+    dispatches of one generate) and the encoder span (marker events)."""
+    import torch
+    from texocr_amd import synth
+    from texocr_amd.model import model_from_dims
+    N = dims.n_tokens(a.height, a.width)
+    m = model_from_dims(dims, dtype=dtype, max_batch=B, max_tokens=N)
+    m.load_state_dict(synth.synth_state_dict(dims, 0))
+    g = torch.Generator(device=dev).manual_seed(4321)
+    img = torch.rand((B, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
+    sec = timed(m, img, a.max_len, warm, steps)
+    out = {"value": round(B / sec, 2), "unit": "images/sec", "ms_per_step": round(1000 * sec, 3), "batch": B, "dtype": dtype, "steps": steps}
+    esz = 2 if dtype == "bf16" else 4
+    eng = m._engine
+    if want_cross:
+        eng.profile(2)
+        m.generate(img, a.max_len)
+        torch.cuda.synchronize()
+        ms, n = eng.profile_read(0)
+        eng.profile(0)
+        algo = B * dims.dec_heads * 2 * N * 64 * esz
+        ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm", "achieved": round(ach, 1),
+                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "algorithmic_bytes_per_launch": algo,
+                           "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n}
+    if want_encoder:
+        eng.profile(True)
+        m.generate(img, a.max_len)
+        torch.cuda.synchronize()
+        ems, _ = eng.profile_read(1)
+        eng.profile(False)
+        peak = 2500.0 if dtype == "bf16" else 157.3
+        tf = enc_flop(dims, B, N) / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
+        out["encoder_ms"] = round(ems, 3)
+        out["encoder_mfma"] = {"achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4)}
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -71,7 +156,7 @@ def main():
     from texocr_amd.config import Dims
     from texocr_amd import synth
     from texocr_amd.model import model_from_dims
-    from texocr_amd.dist import all_gather_rows
+    from texocr_amd.dist import sharded_generate
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -80,7 +165,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (also with one rank)
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -92,13 +178,18 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     imgs = [torch.rand((a.batch, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
             for _ in range(2)]
-    counts = [a.batch] * world
 
     def step(i):
-        toks = model.generate(imgs[i & 1], a.max_len)                    # eos never fires with random weights
+        if dist_on:
+            # every rank decodes its 64 images to max_len with the eos test off; ONE all-gather of the token ids; the
+            # reference's GLOBAL eos break is applied to the gathered batch (texocr_amd/dist.py)
+            toks = sharded_generate(lambda x, n: eng.generate(x, n, None), imgs[i & 1], a.max_len, dims.eos, bos=dims.bos,
+                                    images_are_local=True, global_batch=a.batch * world, force_collective=True)
+        else:
+            toks = model.generate(imgs[i & 1], a.max_len)                # eos never fires for every row with random weights
         if toks.shape[1] != a.max_len:
             raise RuntimeError(f"expected {a.max_len} decode steps, got {toks.shape[1]}")
-        return all_gather_rows(toks, counts) if world > 1 else toks
+        return toks
 
     if not a.no_roofline and rank == 0:
         eng.profile(2); eng.profile(0)          # creates the event pool now, outside the timed region
@@ -109,7 +200,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -125,11 +216,11 @@ def main():
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - s0)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -151,8 +242,8 @@ def main():
             "dtype": a.dtype, "data": "synthetic U[0,1) images, deterministic random-init weights (texocr_amd.synth seed 0)",
             "config": {"workload": f"BASELINE configs[1]: config.yml dims (256-d/8h/4L enc + 4L dec, patch 16, PatchEmbedding C=3), "
                                    f"batch {a.batch}/GPU, {a.height}x{a.width}, greedy max_len={a.max_len}",
-                       "global_batch": a.batch * world, "tokens_per_image": N, "parallelism": f"dp{world} (images sharded, "
-                       "all-gather of token ids)"},
+                       "global_batch": a.batch * world, "tokens_per_image": N,
+                       "parallelism": f"dp{world} (images sharded, " + ("one RCCL all-gather of token ids per step" if dist_on else "single process, no collective") + ")"},
         }
         if not a.no_roofline:
             ms_live, n_live = eng.profile_read(0)          # measured over the timed region above
@@ -164,35 +255,47 @@ def main():
             sms, sn = eng.profile_read(2)
             eng.profile(False)
             algo = a.batch * dims.dec_heads * 2 * N * 64 * esz
-            traffic = None                      # PMC bytes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 passes
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", f"r01_pmc_{a.dtype}_b64.json")))["cross_attention_traffic"]
-                if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N}:
-                    traffic = pm["traffic_bytes"]
-            except Exception:
-                pass
-            # encoder (patch-embed + ViT stack) FLOPs per image, SURVEY 8d: 2(N-1)C*256*D + Le*(N(10DI + 6DF) + 4N^2 I)
-            D_, I_, F_, Le = dims.embed_dim, dims.enc_inner, dims.enc_ffn, dims.enc_layers
-            enc_flop = a.batch * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
+            traffic, traffic_source = None, None   # PMC bytes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 passes
+            for rnd in ("r02", "r01"):
+                fn = os.path.join("profiles", f"{rnd}_pmc_{a.dtype}_b{a.batch}.json")
+                try:
+                    pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]
+                    if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N}:
+                        traffic, traffic_source = pm["traffic_bytes"], fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
+                        break
+                except Exception:
+                    pass
             mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3          # dense TFLOP/s, MI355X_MICROARCH.md
-            enc_tf = enc_flop / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
+            enc_tf = enc_flop(dims, a.batch, N) / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
             ms_pass, n_pass = ms, n
             if n_live > 0:
                 ms, n = ms_live, n_live
             ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
                                   "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                                  "traffic": traffic, "algorithmic_bytes_per_launch": algo,
+                                  "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo,
                                   "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
                                   "timed_over": "the last of the K timed steps (dispatch-bound HIP events)" if n_live > 0 else "separate profiled pass",
                                   "avg_launch_us_profiled_pass": round(ms_pass * 1e3, 2),
                                   "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1),
                                   "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                                                    "frac": round(enc_tf / mfma_peak, 4)}}
+        if world == 1 and not a.no_extras:
+            del model, eng
+            torch.cuda.empty_cache()
+            try:
+                result["fp32_parity_mode"] = side_measurement(dims, "fp32", a.batch, a, dev, 2, 5, False, False)
+                result["fp32_parity_mode"]["note"] = "same workload on the token-exact fp32 engine (tests/test_gpu_parity.py pins it to the reference)"
+                result["b256"] = side_measurement(dims, a.dtype, 256, a, dev, 2, 4, True, False)
+                d4 = Dims(canvas=max(a.height, a.width), embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6)
+                result["cfg4"] = side_measurement(d4, a.dtype, 256, a, dev, 1, 3, True, True)
+                result["cfg4"]["workload"] = "BASELINE configs[3]: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h), batch 256"
+            except Exception as e:                          # a side measurement must never lose the headline line
+                result["extras_error"] = f"{type(e).__name__}: {e}"
         if not a.no_cpu_baseline and world == 1:            # reported at N=1 only (bench contract)
             result["cpu_baseline"] = cpu_baseline(dims, sd_np, a)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -158,27 +158,47 @@ def _same_pad(x: torch.Tensor, k: int, s: int, value: float = 0.0) -> torch.Tens
     return x
 
 
-def std_conv(x: torch.Tensor, w: torch.Tensor, stride: int) -> torch.Tensor:
+def bf16_round(x: torch.Tensor) -> torch.Tensor:
+    """round-to-nearest-even to bfloat16 and back: what one store of the bf16 engine does to an fp32 value"""
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def std_conv(x: torch.Tensor, w: torch.Tensor, stride: int, q=None) -> torch.Tensor:
     """StdConv2d.forward (resnet.py:54-66): weights standardised per output channel (biased variance, eps 1e-6);
-    static symmetric padding when stride == 1 and (k-1) even (utils.py:101-110), dynamic SAME otherwise."""
+    static symmetric padding when stride == 1 and (k-1) even (utils.py:101-110), dynamic SAME otherwise.
+    q: optional rounding applied where the bf16 engine stores (standardised weights, conv output) -- see resnet_backbone."""
     k = w.shape[-1]
     # same ATen call as the reference, so the standardised weights are bit-identical to its
     ws = F.batch_norm(w.reshape(1, w.shape[0], -1), None, None, training=True, momentum=0.0, eps=1e-6).reshape_as(w)
+    if q is not None:
+        ws = q(ws)
     if stride == 1 and (k - 1) % 2 == 0:
-        return F.conv2d(x, ws, None, 1, (k - 1) // 2)
-    return F.conv2d(_same_pad(x, k, stride), ws, None, stride, 0)
+        y = F.conv2d(x, ws, None, 1, (k - 1) // 2)
+    else:
+        y = F.conv2d(_same_pad(x, k, stride), ws, None, stride, 0)
+    return q(y) if q is not None else y
 
 
-def group_norm_act(sd: SD, p: str, x: torch.Tensor, act: bool) -> torch.Tensor:
-    """GroupNormAct (resnet.py:14-35): 32 groups, eps 1e-5, optional ReLU."""
+def group_norm_act(sd: SD, p: str, x: torch.Tensor, act: bool, q=None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNormAct (resnet.py:14-35): 32 groups, eps 1e-5, optional ReLU.  With `res` the residual add and the ReLU
+    behind it (Bottleneck.forward, resnet.py:143-149) are applied before the (optional) rounding, as the engine's fused
+    normalise kernel does."""
     x = F.group_norm(x, 32, sd[f"{p}.weight"], sd[f"{p}.bias"], 1e-5)
-    return F.relu(x) if act else x
+    if res is not None:
+        x = x + res
+    x = F.relu(x) if act else x
+    return q(x) if q is not None else x
 
 
-def resnet_backbone(sd: SD, p: str, img: torch.Tensor) -> torch.Tensor:
-    """ResNetV2(depths=[2,4,6]).forward (resnet.py:200-254) with Bottleneck.forward (:143-149)."""
-    x = std_conv(img, sd[f"{p}.stem.0.weight"], 2)
-    x = group_norm_act(sd, f"{p}.stem.1", x, True)
+def resnet_backbone(sd: SD, p: str, img: torch.Tensor, q=None) -> torch.Tensor:
+    """ResNetV2(depths=[2,4,6]).forward (resnet.py:200-254) with Bottleneck.forward (:143-149).
+
+    q = bf16_round gives a CPU EMULATION of the engine's bf16 mode for this backbone: every tensor the engine stores as bf16
+    (input pixels as a GEMM operand, standardised weights, every conv output, every GroupNorm output) is rounded there, all
+    arithmetic stays fp32.  It is not the reference's arithmetic; it exists to show what bf16 storage alone does to these 45
+    layers with random weights (tests/test_oracle_golden.py, tests/test_gpu_parity.py)."""
+    x = std_conv(q(img) if q is not None else img, sd[f"{p}.stem.0.weight"], 2, q)
+    x = group_norm_act(sd, f"{p}.stem.1", x, True, q)
     x = F.max_pool2d(_same_pad(x, 3, 2, value=-float("inf")), 3, 2)                 # resnet.py:69-79
     for st, depth in enumerate((2, 4, 6)):
         for i in range(depth):
@@ -186,29 +206,29 @@ def resnet_backbone(sd: SD, p: str, img: torch.Tensor) -> torch.Tensor:
             stride = 2 if (i == 0 and st > 0) else 1
             res = x
             if f"{b}.downsample.conv.weight" in sd:
-                res = group_norm_act(sd, f"{b}.downsample.norm", std_conv(x, sd[f"{b}.downsample.conv.weight"], stride), False)
-            y = group_norm_act(sd, f"{b}.block_list.1", std_conv(x, sd[f"{b}.block_list.0.weight"], 1), True)
-            y = group_norm_act(sd, f"{b}.block_list.3", std_conv(y, sd[f"{b}.block_list.2.weight"], stride), True)
-            y = group_norm_act(sd, f"{b}.block_list.5", std_conv(y, sd[f"{b}.block_list.4.weight"], 1), False)
-            x = F.relu(y + res)
+                res = group_norm_act(sd, f"{b}.downsample.norm", std_conv(x, sd[f"{b}.downsample.conv.weight"], stride, q), False, q)
+            y = group_norm_act(sd, f"{b}.block_list.1", std_conv(x, sd[f"{b}.block_list.0.weight"], 1, q), True, q)
+            y = group_norm_act(sd, f"{b}.block_list.3", std_conv(y, sd[f"{b}.block_list.2.weight"], stride, q), True, q)
+            x = group_norm_act(sd, f"{b}.block_list.5", std_conv(y, sd[f"{b}.block_list.4.weight"], 1, q), True, q, res=res)
     return x
 
 
-def hybrid_embed(sd: SD, img: torch.Tensor) -> torch.Tensor:
+def hybrid_embed(sd: SD, img: torch.Tensor, q=None) -> torch.Tensor:
     """HybridEmbedding.forward (encoder.py:65-72): backbone, 1x1 proj conv (+bias), flatten(2).transpose(1,2)."""
-    f = resnet_backbone(sd, "encoder.patch_embed.backbone_net", img)
-    f = F.conv2d(f, sd["encoder.patch_embed.proj.weight"], sd["encoder.patch_embed.proj.bias"])
+    f = resnet_backbone(sd, "encoder.patch_embed.backbone_net", img, q)
+    w = sd["encoder.patch_embed.proj.weight"]
+    f = F.conv2d(f, q(w) if q is not None else w, sd["encoder.patch_embed.proj.bias"])
     return f.flatten(2).transpose(1, 2)
 
 
-def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None, grid_w: Optional[int] = None) -> torch.Tensor:
+def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None, grid_w: Optional[int] = None, backbone_q=None) -> torch.Tensor:
     """VisionTransformer.forward (encoder.py:128-152), head = Identity.  grid_w = patches per row of the max
-    canvas (canvas_w / 16); defaults to a square canvas."""
+    canvas (canvas_w / 16); defaults to a square canvas.  backbone_q: see resnet_backbone (bf16 emulation, hybrid only)."""
     B, C, H, W = img.shape
     hybrid = "encoder.patch_embed.backbone_net.stem.0.weight" in sd
     P = 16 if hybrid else sd["encoder.patch_embed.proj.weight"].shape[-1]
     grid = grid_w or int(round(math.sqrt(sd["encoder.pos_embed"].shape[1] - 1)))
-    x = hybrid_embed(sd, img) if hybrid else patch_embed(sd, img)
+    x = hybrid_embed(sd, img, backbone_q) if hybrid else patch_embed(sd, img)
     x = torch.cat([sd["encoder.cls_token"].expand(B, -1, -1), x], dim=1)    # :133-134
     x = x + sd["encoder.pos_embed"][:, pos_ids(H // P, W // P, grid)]       # :143
     x = stack(sd, "encoder.attn_layers", kinds_of(sd, "encoder.attn_layers"), x, None, False, trace)

@@ -128,14 +128,25 @@ def test_eos_global_break_golden():
     assert np.array_equal(free.cpu().numpy(), g["free_tokens"])
 
 
-def test_sliding_window_is_refused():
+def test_sliding_window_matches_reference():
+    """max_len > decoder.max_len: the reference slides its window (decoder.py:99-100).  The facades follow it by re-running
+    the window through the cached path for every further token; the one-call C entry point (txo_generate) still refuses."""
     meta, g = load_golden("sliding_window")
     d, sd, m = build(meta)
     img = images(meta).cuda()
+    assert meta["max_len"] > d.max_len
+    t = m.generate(img, meta["max_len"])
+    assert t.shape == (1, meta["max_len"])
+    assert np.array_equal(t.cpu().numpy(), g["tokens"])
+    # the same through decoder.generate with explicit start tokens
+    enc = m.encoder(img)
+    start = torch.full((1, 1), d.bos, dtype=torch.int64, device="cuda")
+    t2 = m.decoder.generate(start, d.eos, meta["max_len"], enc=enc)
+    assert np.array_equal(t2.cpu().numpy(), g["tokens"])
     with pytest.raises(ValueError, match="slide"):
-        m.generate(img, meta["max_len"])              # reference returns (1, 20) by sliding; a KV cache cannot
-    ok = m.generate(img, d.max_len)                   # within the table it must agree with the reference prefix
-    assert np.array_equal(ok.cpu().numpy(), g["tokens"][:, :d.max_len])
+        m._engine.generate(img, meta["max_len"], d.eos)
+    with pytest.raises(ValueError, match="slide|position"):
+        m._engine.decode_step(d.max_len, torch.zeros(1, dtype=torch.int64, device="cuda"))
 
 
 def test_hybrid_resnet_embedder_golden():
@@ -175,14 +186,21 @@ def test_hybrid_oracle_wider_image_and_bf16():
     ref_t, ref_l = cpu_ref.generate_cached(sdt, img, d.bos, d.eos, 16, collect_logits=True, enc=enc_ref)
     toks, logits = m.generate(img.cuda(), 16, return_logits=True)
     assert_tokens_exact_up_to_margin(toks.cpu().numpy(), ref_t.numpy(), ref_l, thr=1e-4)
+    # bf16 mode.  Against the fp32 oracle the random-weight backbone deviates by about a fifth -- and so does a CPU emulation
+    # that only ROUNDS what the engine stores as bf16 (cpu_ref.resnet_backbone(q=bf16_round): fp32 arithmetic everywhere;
+    # tests/test_oracle_golden.py pins that figure).  The kernels are therefore judged against the emulation: the engine's
+    # bf16 encoder output must sit close to the emulated one, closer by far than either sits to the fp32 result.
     d2, sd2, mb = build(d, seed=9, dtype="bf16", max_batch=3, max_tokens=1 + 4 * 20)
-    encb = mb.encoder(img.cuda())
-    err = (encb.cpu() - enc_ref).abs()
-    rel = float(err.mean() / enc_ref.abs().mean())
-    print(f"hybrid bf16: mean|err|/mean|ref| = {rel:.4f}, max|err| = {float(err.max()):.3f}, max|ref| = {float(enc_ref.abs().max()):.3f}")
-    # A CPU emulation that rounds weights and every conv / norm output of this random-weight backbone to bf16 shows
-    # the same 0.19-0.21 mean relative deviation: it is the network's sensitivity, not the kernels'.
-    assert rel < 0.35, rel
+    encb = mb.encoder(img.cuda()).cpu()
+    enc_emu = cpu_ref.encode(sdt, img, grid_w=d.grid, backbone_q=cpu_ref.bf16_round)
+    scale = float(enc_ref.abs().mean())
+    rel_fp32 = float((encb - enc_ref).abs().mean()) / scale
+    rel_emu = float((encb - enc_emu).abs().mean()) / scale
+    emu_fp32 = float((enc_emu - enc_ref).abs().mean()) / scale
+    print(f"hybrid bf16 encoder output, mean|diff|/mean|ref|: engine vs fp32 oracle {rel_fp32:.4f}, bf16-storage emulation vs fp32 "
+          f"oracle {emu_fp32:.4f}, engine vs emulation {rel_emu:.4f}")
+    assert rel_emu < 0.1, rel_emu
+    assert rel_emu < 0.5 * rel_fp32 and abs(rel_fp32 - emu_fp32) < 0.5 * emu_fp32
 
 
 # ------------------------------------------------------------------------------------------------
@@ -315,15 +333,15 @@ def test_errors_and_state_dict_checks():
              bos=30, eos=29, pad=31)
     sd = synth.synth_state_dict(d, 1)
     m = model_from_dims(d, max_batch=2)
-    with pytest.raises(RuntimeError, match="not finalized|weights"):
-        m.encoder(torch.zeros(1, 3, 32, 32, device="cuda"))
+    # as in the reference, a freshly created model is usable (default-initialised parameters)
+    assert bool(torch.isfinite(m.encoder(torch.rand(1, 3, 32, 32, device="cuda"))).all())
     bad = dict(sd)
     bad["encoder.attn_layers.layers.1.0.weight"] = sd["encoder.attn_layers.layers.0.0.weight"] + 1
     with pytest.raises(ValueError, match="shares ONE LayerNorm"):
         m.load_state_dict(bad)
     m = model_from_dims(d, max_batch=2)
     miss = {k: v for k, v in sd.items() if k != "decoder.net.to_logits.bias"}
-    with pytest.raises(RuntimeError, match="missing"):
+    with pytest.raises(RuntimeError, match="(?i)missing"):
         m.load_state_dict(miss)
     m = model_from_dims(d, max_batch=2)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})     # torch tensors, aliases included
@@ -332,8 +350,7 @@ def test_errors_and_state_dict_checks():
             m.encoder(torch.zeros(*shape, device="cuda"))
     with pytest.raises(ValueError, match="CUDA"):
         m.encoder(torch.zeros(1, 3, 32, 32))
-    with pytest.raises(ValueError):
-        m.generate(torch.zeros(1, 3, 32, 32, device="cuda"), 9)
+    assert m.generate(torch.zeros(1, 3, 32, 32, device="cuda"), 9).shape == (1, 9)   # beyond max_length: sliding window
     with pytest.raises(ValueError, match="enc"):
         m.decoder.net(torch.zeros(1, 2, dtype=torch.long, device="cuda"))
     with pytest.raises(NotImplementedError):
@@ -429,6 +446,81 @@ def test_wrapper_end_to_end(tmp_path):
     assert toks2 == toks and text2 == text
     toks3, _ = w(img, max_len=20, temp=0.3, seed=5)           # the reference's default decode: sampling
     assert len(toks3) == 19
+
+
+def test_wrapper_matches_reference_wrapper_fixture(tmp_path):
+    """N3 pinned: the reference's TeXOCRWrapper.__call__ (ocr_model.py:94-110) was run on a drawn image through the default
+    factory (hybrid embedder); this build's wrapper must return the same tokens and the same LaTeX string, inside the
+    positional table and beyond it (sliding window, max_len 40 > max_length 24)."""
+    import json, os
+    from PIL import Image
+    from texocr_amd.config import reference_config
+    from texocr_amd.tokenizer import RegExTokenizer
+    from texocr_amd.wrapper import TeXOCRWrapper
+    meta, g = load_golden("wrapper_160x48")
+    d = Dims(**meta["dims"])
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(d, meta["weight_seed"]).items()}
+    ckpt = tmp_path / "checkpoint_e1.pth"
+    torch.save({"model_state_dict": sd, "optimizer_state_dict": {}, "epoch": 1}, ckpt)
+    v = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tokenizer_vocab_1k.json")))
+    RegExTokenizer.from_tables(v["vocab_size"], v["special_tokens"], v["merges"]).save(str(tmp_path / "vocab.txt"))
+    cfg = reference_config(max_length=256)                    # the checkpoint's positional table (24) overrides this
+    cfg["tokenizer_path"], cfg["model_path"] = str(tmp_path / "vocab.txt"), str(ckpt)
+    w = TeXOCRWrapper(cfg)
+    assert w.model.decoder.max_len == d.max_len == 24
+    img = Image.fromarray(g["pixels"])
+    for case in meta["cases"]:
+        toks, text = w(img, max_len=case["max_len"], decode="greedy")
+        assert toks == g[f"tokens_{case['name']}"].tolist(), case["name"]
+        assert text == case["text"]
+
+
+def test_custom_ops_and_module_state_dict():
+    """The boundary as north_star words it: torch.ops.texocr.* over the C ABI, and OCRModel as an nn.Module whose
+    state_dict() has the reference's key layout (aliased shared-LayerNorm keys included) and round-trips."""
+    from texocr_amd.model import model_from_dims
+    meta, g = load_golden("tiny")
+    d, sd, m = build(meta)
+    assert isinstance(m, torch.nn.Module) and isinstance(m.encoder, torch.nn.Module) and isinstance(m.decoder.net, torch.nn.Module)
+    own = m.state_dict()
+    assert list(own.keys()) == [k for k, _, _ in synth.state_dict_layout(d)] == [k for k, _, _ in meta["state_dict_layout"]]
+    for k, v in own.items():
+        assert v.is_cuda and np.array_equal(v.cpu().numpy(), sd[k]), k
+    # aliases are ONE parameter (attention.py:200,221): parameters() counts it once
+    assert own["encoder.attn_layers.layers.3.0.weight"].data_ptr() == own["encoder.attn_layers.layers.0.0.weight"].data_ptr()
+    n_unique = sum(int(np.prod(s)) for k, s, c in synth.state_dict_layout(d) if k == c)
+    assert sum(p.numel() for p in m.parameters()) == n_unique
+    # the operators, called directly
+    img = images(meta).cuda()
+    eid = m._engine.id
+    enc = torch.ops.texocr.encode(img, eid)
+    np.testing.assert_allclose(enc.cpu().numpy(), g["enc"], atol=2e-5)
+    toks, n, logits = torch.ops.texocr.generate(img, eid, 16, d.eos, True)
+    assert n.device.type == "cpu" and int(n) == 16 and toks.shape == (2, 16) and logits.shape == (2, 16, d.vocab)
+    assert np.array_equal(toks.cpu().numpy(), g["tokens"])
+    np.testing.assert_allclose(logits.cpu().numpy(), g["step_logits"], atol=3e-5)
+    toks2, n2, lg2 = torch.ops.texocr.generate_from_enc(enc, eid, 16, -1, False)
+    assert torch.equal(toks2, toks) and lg2.shape[0] == 0
+    torch.ops.texocr.decode_begin(enc, eid)
+    ref = torch.from_numpy(g["tokens"].astype(np.int64)).cuda()
+    tok = torch.full((2,), d.bos, dtype=torch.int64, device="cuda")
+    for t in range(4):
+        lg, nxt = torch.ops.texocr.decode_step(tok, eid, t, 2, True)
+        np.testing.assert_allclose(lg.cpu().numpy(), g["step_logits"][:, t], atol=3e-5)
+        assert torch.equal(nxt, ref[:, t])
+        tok = nxt
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.texocr.encode(img.cpu(), eid)
+    # state_dict round trip into a second model; in-place edits need sync_weights()
+    m2 = model_from_dims(d, max_batch=8)
+    assert not torch.equal(m2.generate(img, 16), toks)            # default-initialised weights: another model
+    res = m2.load_state_dict(m.state_dict())
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(m2.generate(img, 16), toks)
+    with torch.no_grad():
+        m2.decoder.net.to_logits.bias[5] += 100.0
+    m2.sync_weights()
+    assert bool((m2.generate(img, 4) == 5).all())
 
 
 def test_beam_search_extension():
@@ -649,3 +741,144 @@ def test_persistent_decode_global_eos_break():
     d2, sd2, m2 = build(d2, seed=11, max_batch=20)
     t2p, t2l = _both_paths(m2, img, 64)
     assert t2p.shape == (20, 1) and torch.equal(t2p, t2l)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs 2 (bf16), 4 and 5 at their full sizes
+# ------------------------------------------------------------------------------------------------
+CFG4 = dict(canvas=672, embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6)
+
+
+def test_cfg4_vit_base_golden():
+    """G10: ViT-Base 12L/768d/12h encoder + 6L/768d/12h decoder, B=2, 224x672, 8 greedy steps captured from the
+    reference (encoder.py:75-121, decoder.py:148-173); fp32 parity mode must reproduce it, bf16 mode is measured."""
+    meta, g = load_golden("cfg4_b2_224x672")
+    d, sd, m = build(meta, max_batch=2, max_tokens=589)
+    img = images(meta).cuda()
+    enc = m.encoder(img)
+    assert enc.shape == (2, 589, 768)
+    np.testing.assert_allclose(enc[:, ::16, ::4].cpu().numpy(), g["enc_rows"], atol=1e-4)
+    np.testing.assert_allclose(enc.double().sum((1, 2)).cpu().numpy(), g["enc_sum"], rtol=0, atol=0.1)
+    toks, logits = m.generate(img, 8, return_logits=True)
+    assert np.array_equal(toks.cpu().numpy(), g["tokens"])
+    err = float(np.abs(logits.cpu().numpy() - g["step_logits"]).max())
+    assert err < 1e-3, err                                       # north_star: logits within 1e-3 in fp32
+    del m
+    _, _, mb = build(meta, dtype="bf16", max_batch=2, max_tokens=589)
+    tb, lb = mb.generate(img, 8, return_logits=True)
+    agree = float((tb.cpu().numpy() == g["tokens"]).mean())
+    lerr = float(np.abs(lb.cpu().numpy() - g["step_logits"]).max())
+    print(f"cfg4 bf16 vs reference: free-running token agreement {agree:.3f} over 2x8, max |dlogit| {lerr:.3f} (fixture margin >= 0.032)")
+    assert lerr < 0.5 and agree >= 0.5
+
+
+def test_cfg4_full_size_b256():
+    """BASELINE configs[3] at size: B=256, 224x672.  fp32: the two fixture images as rows 100 and 7 of a 256-image batch
+    must decode to the reference's tokens / logits (rows never interact; decoder.py:115 is the only cross-row operation).
+    bf16: 256 full steps -- deterministic, permutation-equivariant, token range."""
+    meta, g = load_golden("cfg4_b2_224x672")
+    d = Dims(**meta["dims"])
+    sd = synth.synth_state_dict(d, meta["weight_seed"])
+    from texocr_amd.model import model_from_dims
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    img = torch.rand((256, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[100], img[7] = fix[0], fix[1]
+    m = model_from_dims(d, dtype="fp32", max_batch=256, max_tokens=589)
+    m.load_state_dict(sd)
+    toks, logits = m.generate(img, 8, return_logits=True)
+    assert toks.shape == (256, 8)
+    assert np.array_equal(toks[[100, 7]].cpu().numpy(), g["tokens"])
+    assert float(np.abs(logits[[100, 7]].cpu().numpy() - g["step_logits"]).max()) < 1e-3
+    del m
+    torch.cuda.empty_cache()
+    mb = model_from_dims(d, dtype="bf16", max_batch=256, max_tokens=589)
+    mb.load_state_dict(sd)
+    t1 = mb.generate(img, 256)
+    assert t1.shape == (256, 256) and int(t1.min()) >= 0 and int(t1.max()) < d.vocab
+    assert torch.equal(mb.generate(img, 256), t1)
+    perm = torch.randperm(256, device="cuda", generator=gen)
+    assert torch.equal(mb.generate(img[perm].contiguous(), 256), t1[perm])
+
+
+def test_cfg5_full_size_beam5_bucketed():
+    """BASELINE configs[4] at size: 128 images, widths 224..896 in steps of 64 (the renderer pads widths to multiples of
+    64, render_data.py:85-86), bucketed by exact size like BucketBatchSampler (dataset.py:281-326), beam search k=5
+    (a build extension: the reference has none), max_len 256.  Anchors: the oracle's independent CPU beam search on a
+    4-image subset (fp32), and the composition bucket -> shard -> beam -> gather used on a node."""
+    cpu_ref = _oracle()
+    from texocr_amd.dist import generate_bucketed, sharded_generate_bucketed
+    from texocr_amd.model import model_from_dims
+    d = Dims(canvas=896)
+    sd = synth.synth_state_dict(d, 0)
+    rng = np.random.Generator(np.random.PCG64(55))
+    widths = rng.choice(np.arange(224, 897, 64), size=128)
+    gen = torch.Generator(device="cuda").manual_seed(8)
+    imgs = [torch.rand((3, 224, int(w)), generator=gen, device="cuda") for w in widths]
+    biggest = max(np.bincount(widths // 64).max(), 1)
+    mb = model_from_dims(d, dtype="bf16", max_batch=int(biggest) * 5, max_tokens=785)
+    mb.load_state_dict(sd)
+    rows = generate_bucketed(lambda b: mb.generate(b, 256, beam=5), imgs, max_batch=int(biggest))
+    assert len(rows) == 128 and all(r.ndim == 1 and 1 <= r.shape[0] <= 256 for r in rows)
+    assert all(int(r.min()) >= 0 and int(r.max()) < d.vocab for r in rows)
+    rows2 = generate_bucketed(lambda b: mb.generate(b, 256, beam=5), imgs, max_batch=int(biggest))
+    assert all(torch.equal(a, b) for a, b in zip(rows, rows2))
+    # the node-level composition at world size 1 (no process group): same rows
+    rows3 = sharded_generate_bucketed(lambda b, n: mb.generate(b, n, beam=5), imgs, 256, d.eos, bos=d.bos, max_batch=int(biggest), beam=True)
+    assert all(torch.equal(a, b) for a, b in zip(rows, rows3))
+    del mb
+    # fp32 against the oracle's beam search: one image of four different widths, 12 steps
+    pick = [int(np.nonzero(widths == w)[0][0]) for w in sorted(set(widths.tolist()))[:4]]
+    mf = model_from_dims(d, dtype="fp32", max_batch=5, max_tokens=785)
+    mf.load_state_dict(sd)
+    sdt = cpu_ref.to_torch_sd(sd)
+    for i in pick:
+        x = imgs[i][None].contiguous()
+        beams, scores = mf.generate(x, 12, beam=5, return_beams=True)
+        enc = cpu_ref.encode(sdt, x.cpu())
+        ref_beams, ref_scores = cpu_ref.beam_search_cached(sdt, enc, d.bos, d.eos, 12, 5)
+        assert np.array_equal(beams[0].cpu().numpy(), ref_beams[0].numpy()), i
+        np.testing.assert_allclose(scores[0].cpu().numpy(), ref_scores[0].numpy(), atol=2e-3)
+
+
+def test_cfg2_full_size_bf16():
+    """BASELINE configs[1] in the mode the headline number is quoted in: bf16, B=64, 224x672, 256 steps -- deterministic,
+    permutation-equivariant; measured agreement with the token-exact fp32 engine (teacher-forced on the fp32 tokens)."""
+    from texocr_amd.model import model_from_dims
+    d = Dims(canvas=672)
+    sd = synth.synth_state_dict(d, 0)
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    img = torch.rand((64, 3, 224, 672), generator=gen, device="cuda")
+    mb = model_from_dims(d, dtype="bf16", max_batch=64, max_tokens=589)
+    mb.load_state_dict(sd)
+    t1 = mb.generate(img, 256)
+    assert t1.shape == (64, 256) and int(t1.min()) >= 0 and int(t1.max()) < d.vocab
+    assert torch.equal(mb.generate(img, 256), t1)
+    perm = torch.randperm(64, device="cuda", generator=gen)
+    assert torch.equal(mb.generate(img[perm].contiguous(), 256), t1[perm])
+    mf = model_from_dims(d, dtype="fp32", max_batch=64, max_tokens=589)
+    mf.load_state_dict(sd)
+    tf_, lf = mf.generate(img, 64, return_logits=True)
+    # teacher-forced bf16 logits on the fp32 engine's tokens
+    prefix = torch.cat([torch.full((64, 1), d.bos, dtype=torch.int64, device="cuda"), tf_[:, :-1]], 1)
+    lb = mb.decoder.net(prefix, enc=mb.encoder(img))
+    agree = float((lb.argmax(-1) == tf_).float().mean())
+    err = float((lb - lf).abs().max())
+    first = float((t1[:, 0] == tf_[:, 0]).float().mean())
+    print(f"cfg2 bf16 vs fp32 engine, B=64 x 64 steps: teacher-forced top-1 agreement {agree:.4f}, max |dlogit| {err:.3f}, "
+          f"free-running first-token agreement {first:.3f}")
+    assert agree > 0.9 and err < 0.3
+
+
+def test_torch_free_c_program_on_the_c_abi(tmp_path):
+    """examples/generate_tiny.c: plain C + HIP runtime API, no Python in the process: loads the tiny fixture's weights one
+    reference key at a time, runs txo_generate and compares the tokens with the reference's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from texocr_amd import build as b
+    exe = b.build_example(verbose=False)
+    blob = str(tmp_path / "tiny.bin")
+    subprocess.run([sys.executable, os.path.join(root, "examples", "make_tiny_blob.py"), blob], check=True, capture_output=True)
+    r = subprocess.run([exe, blob], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "match the reference" in r.stdout

@@ -181,3 +181,108 @@ def test_generate_bucketed_groups_by_exact_size():
     assert sorted(calls) == sorted([(3, 1, 16, 32), (1, 1, 16, 32), (2, 1, 16, 64), (1, 1, 32, 32)])
     for im, o in zip(imgs, out):
         assert int(o[0]) == int(im.sum() * 100) and o.shape == (3,)
+
+
+def test_custom_ops_registered_with_fake_impls():
+    """torch.ops.texocr.* exist without a GPU and their fake implementations give the output shapes (what torch.compile /
+    FakeTensorMode need); real calls on CPU tensors are refused (no CPU fallback)."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from texocr_amd import ops
+    d = Dims(canvas=672)
+
+    class Stub:                                                  # what a fake implementation needs of an engine: its dims
+        dims, device = d, 0
+    stub = Stub()
+    eid = ops.register_engine(stub)
+    for name in ("encode", "decode_begin", "decode_step", "generate", "generate_from_enc", "generate_beam"):
+        assert hasattr(torch.ops.texocr, name)
+    with FakeTensorMode():
+        img = torch.empty((4, 3, 224, 672))
+        enc = torch.ops.texocr.encode(img, eid)
+        assert enc.shape == (4, 589, 256) and enc.dtype == torch.float32
+        toks, n, logits = torch.ops.texocr.generate(img, eid, 256, d.eos, True)
+        assert toks.shape == (4, 256) and toks.dtype == torch.int64 and n.shape == (1,) and logits.shape == (4, 256, 1000)
+        toks, n, logits = torch.ops.texocr.generate_from_enc(enc, eid, 32, -1, False)
+        assert toks.shape == (4, 32) and logits.shape == (0, 32, 1000)
+        lg, nxt = torch.ops.texocr.decode_step(torch.empty((4,), dtype=torch.int64), eid, 0, 4, True)
+        assert lg.shape == (4, 1000) and nxt.shape == (4,) and nxt.dtype == torch.int64
+        best, scores, allt, n = torch.ops.texocr.generate_beam(img, eid, 5, 64, d.eos, True)
+        assert best.shape == (4, 64) and scores.shape == (4, 5) and allt.shape == (20, 64)
+    with pytest.raises((ValueError, RuntimeError)):
+        torch.ops.texocr.encode(torch.zeros(1, 3, 224, 224), eid)            # CPU tensor: refused, never computed on the host
+    ops.unregister_engine(eid)
+    with pytest.raises(RuntimeError, match="no live engine"):
+        torch.ops.texocr.encode(torch.zeros(1, 3, 224, 224), eid)
+
+
+def _fake_rows(batch, max_len, eos):
+    """per-image token rows that depend on the image only (so sharding cannot change them): eos appears at a position
+    derived from the image, junk continues behind it as in the reference's greedy loop"""
+    out = torch.empty((batch.shape[0], max_len), dtype=torch.int64)
+    for b in range(batch.shape[0]):
+        key = int(batch[b].sum().item() * 1000) % 97
+        row = (torch.arange(max_len) * 7 + key) % 50 + 10
+        row[3 + key % (max_len - 4)] = eos
+        out[b] = row
+    return out
+
+
+def _fake_greedy(batch, max_len):
+    return _fake_rows(batch, max_len, 5)
+
+
+def _fake_beam(batch, max_len):
+    """beam-search shape: finished rows repeat eos; the call returns only as many columns as its LOCAL batch needs"""
+    rows = _fake_rows(batch, max_len, 5)
+    first = (rows == 5).float().argmax(dim=1)
+    for b in range(rows.shape[0]):
+        rows[b, first[b] + 1:] = 5
+    return rows[:, : int(first.max()) + 1]
+
+
+def _bucket_worker(rank, world, port, beam, q):
+    import torch.distributed as dist
+    from texocr_amd.dist import sharded_generate_bucketed
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        imgs = _bucket_images()
+        rows = sharded_generate_bucketed(_fake_beam if beam else _fake_greedy, imgs, 24, 5, max_batch=2, beam=beam)
+        q.put((rank, [r.tolist() for r in rows]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _bucket_images():
+    g = torch.Generator().manual_seed(3)
+    widths = [32, 64, 32, 96, 64, 32, 32, 64, 96, 32, 32]          # three buckets: 6 / 3 / 2 images
+    return [torch.rand((1, 16, w), generator=g) for w in widths]
+
+
+@pytest.mark.parametrize("beam", [False, True])
+def test_sharded_generate_bucketed_gloo_world2(beam):
+    """BASELINE config 5's composition (bucket -> shard within the bucket -> greedy / beam -> ONE gather) on 2 ranks gives
+    what one process gives; with max_batch=2 per rank the 6-image bucket becomes two global batches of 4 and 2."""
+    import torch.multiprocessing as mp
+    from texocr_amd.dist import sharded_generate_bucketed, bucket_plan
+    imgs = _bucket_images()
+    plan1 = bucket_plan(imgs, 4)
+    assert [len(c) for c in plan1] == [4, 2, 3, 2] and sorted(sum(plan1, [])) == list(range(len(imgs)))
+    # the single-process result uses the SAME global batches (max_batch * world images): that is what the ranks shard
+    single = sharded_generate_bucketed(_fake_beam if beam else _fake_greedy, imgs, 24, 5, max_batch=4, beam=beam)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (1 if beam else 0) + os.getpid() % 200
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, beam, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [r.tolist() for r in single]
+    # rows of one global batch share their length (GLOBAL break / longest beam); different batches differ
+    lens = [len(r) for r in got[0]]
+    for chunk in plan1:
+        assert len({lens[i] for i in chunk}) == 1
+    assert all(5 in r for r in got[0])

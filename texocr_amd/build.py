@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtexocr_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["common.h", "conv.h", "gemm_big.h", "gemm_pp.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "step.h"]
+HEADERS = ["common.h", "conv.h", "gemm_big.h", "gemm_pp.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "step.h", "persist.h"]
 
 
 def _stale() -> bool:
@@ -34,5 +34,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def build_example(verbose: bool = True) -> str:
+    """examples/generate_tiny: the torch-free C host program on the C ABI (plain gcc; HIP runtime API for device memory)."""
+    root = os.path.dirname(HERE)
+    src, out = os.path.join(root, "examples", "generate_tiny.c"), os.path.join(root, "examples", "generate_tiny")
+    if os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(src), os.path.getmtime(OUT)):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-std=c99", "-O2", "-I" + os.path.join(root, "include"), "-I" + os.path.join(rocm, "include"), src,
+           "-L" + HERE, "-ltexocr_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/../texocr_amd", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-o", out]
+    if verbose:
+        print("[texocr_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    build_example()

@@ -40,10 +40,11 @@ def global_eos_steps(tokens: torch.Tensor, eos: Optional[int], bos: Optional[int
     return int(idx[0].item()) + 1 if idx.numel() else T
 
 
-def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch.Tensor:
-    """All-gather row blocks of possibly different heights (pads to the tallest, one collective)."""
+def all_gather_rows(local: torch.Tensor, counts: List[int], group=None, force: bool = False) -> torch.Tensor:
+    """All-gather row blocks of possibly different heights (pads to the tallest, one collective).  force: issue the
+    collective even in a one-rank group (bench.py under torchrun --nproc-per-node 1 times the RCCL call itself)."""
     world = len(counts)
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return local
     tall = max(counts)
     if local.shape[0] < tall:
@@ -59,7 +60,8 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None) -> torch
 
 def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images: torch.Tensor, max_len: int,
                      eos: Optional[int], bos: Optional[int] = None, group=None,
-                     images_are_local: bool = False, global_batch: Optional[int] = None, gather_logits: bool = False):
+                     images_are_local: bool = False, global_batch: Optional[int] = None, gather_logits: bool = False,
+                     force_collective: bool = False):
     """Data-parallel generate.
 
     generate_local(img_shard, max_len) -> (b_local, max_len) int64 tokens decoded WITHOUT the eos break
@@ -91,10 +93,10 @@ def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor]
     toks, lg = unpack(generate_local(local, max_len))
     if toks.shape[1] != max_len:
         raise ValueError("generate_local must decode exactly max_len steps (eos break disabled)")
-    full = all_gather_rows(toks, counts, group)
+    full = all_gather_rows(toks, counts, group, force=force_collective)
     n = global_eos_steps(full, eos, bos)
     if gather_logits:
-        return full[:, :n], all_gather_rows(lg, counts, group)[:, :n]
+        return full[:, :n], all_gather_rows(lg, counts, group, force=force_collective)[:, :n]
     return full[:, :n]
 
 
@@ -115,4 +117,77 @@ def generate_bucketed(generate_fn: Callable[[torch.Tensor], torch.Tensor], image
             toks = generate_fn(torch.stack([images[i] for i in part]).contiguous())
             for j, i in enumerate(part):
                 out[i] = toks[j]
+    return out
+
+
+def bucket_plan(images, global_batch: int) -> List[List[int]]:
+    """Indices of `images` grouped like the reference's BucketBatchSampler (data_wrangling/dataset.py:281-326: one bucket per
+    exact (w, h), :306-310) and cut into batches of at most `global_batch` images; buckets in sorted (H, W) order."""
+    buckets = {}
+    for i, im in enumerate(images):
+        if im.ndim != 3:
+            raise ValueError("each image must be (C, H, W)")
+        buckets.setdefault((int(im.shape[1]), int(im.shape[2])), []).append(i)
+    plan = []
+    for _, idx in sorted(buckets.items()):
+        for lo in range(0, len(idx), global_batch):
+            plan.append(idx[lo: lo + global_batch])
+    return plan
+
+
+def sharded_generate_bucketed(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images, max_len: int,
+                              eos: Optional[int], bos: Optional[int] = None, group=None, max_batch: int = 64,
+                              beam: bool = False):
+    """BASELINE config 5 across the ranks of one node: variable-width images are bucketed by exact size, every batch of a
+    bucket is sharded ACROSS the ranks (so all ranks run the same shapes at the same time), each rank decodes its shard
+    (greedy, or beam search whose beams stay on their image's rank), and ONE all-gather returns every batch's token rows
+    to every rank.  Returns one 1-D token tensor per image, in the order of `images`.
+
+    generate_local(batch (b, C, H, W), max_len) -> (b, n) int64 tokens.
+      beam=False: greedy WITHOUT the eos break (n == max_len, e.g. ``lambda x, n: engine.generate(x, n, eos=None)``); the
+        reference's GLOBAL break (decoder.py:115-116) is applied per batch after the gather, over the rows of ALL ranks.
+      beam=True: the engine's beam search with its eos handling on (n <= max_len: the local loop stops when every beam of
+        every LOCAL image is finished; a finished beam only repeats eos, at no cost, so rows are padded with eos up to the
+        batch's longest shard -- what an unsharded run of the whole batch returns).
+    `images` is the GLOBAL list (every rank holds it, or at least the images of its own shards)."""
+    if beam and eos is None:
+        raise ValueError("beam search needs an eos token")
+    ready = dist.is_initialized()
+    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if ready else (1, 0)
+    plan = bucket_plan(images, max_batch * world)
+    dev = images[0].device
+    blocks, talls = [], []
+    for chunk in plan:
+        tall = (len(chunk) + world - 1) // world
+        lo, hi = shard_bounds(len(chunk), rank, world)
+        block = torch.full((tall, max_len + 1), eos if (beam and eos is not None) else 0, dtype=torch.int64, device=dev)
+        block[:, max_len] = 0
+        if hi > lo:
+            toks = generate_local(torch.stack([images[i] for i in chunk[lo:hi]]).contiguous(), max_len)
+            if toks.shape[0] != hi - lo or toks.shape[1] > max_len or (not beam and toks.shape[1] != max_len):
+                raise ValueError("generate_local returned an unexpected shape")
+            block[: hi - lo, : toks.shape[1]] = toks
+            block[: hi - lo, max_len] = toks.shape[1]
+        blocks.append(block)
+        talls.append(tall)
+    local = torch.cat(blocks, dim=0)
+    if world > 1:
+        full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+        full = full.view(world, local.shape[0], max_len + 1)
+    else:
+        full = local[None]
+    out = [None] * len(images)
+    row0 = 0
+    for chunk, tall in zip(plan, talls):
+        rows, lens = [], []
+        for r in range(world):
+            lo, hi = shard_bounds(len(chunk), r, world)
+            rows.append(full[r, row0: row0 + (hi - lo), :max_len])
+            lens.append(full[r, row0: row0 + (hi - lo), max_len])
+        toks = torch.cat(rows, dim=0)                                 # the batch's rows in chunk order
+        n = int(torch.cat(lens).max().item()) if beam else global_eos_steps(toks, eos, bos)
+        for j, i in enumerate(chunk):
+            out[i] = toks[j, :n]
+        row0 += tall
     return out

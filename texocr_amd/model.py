@@ -1,39 +1,48 @@
 """Drop-in call surface of the reference's OCRModel / VisionEncoder / AutoRegressiveDecoder for the
-``generate()`` hot path, backed by the HIP engine behind the C ABI (include/texocr.h).
+``generate()`` hot path, backed by the HIP engine behind the C ABI (include/texocr.h) through the
+``torch.ops.texocr.*`` custom operators (texocr_amd/ops.py).
 
 Mirrors (reference file:line):
-  OCRModel(encoder, decoder, bos_token, eos_token, trg_pad_idx, device)   model/ocr_model.py:16-32
+  OCRModel(encoder, decoder, bos_token, eos_token, trg_pad_idx, device)   model/ocr_model.py:16-32   (an nn.Module)
   OCRModel.generate(src, max_len, temp=0.3)                               model/ocr_model.py:46-66
   model.encoder(src) -> (B, N, D)                                         model/encoder.py:128-152
   model.decoder.generate(start_tokens, eos_tok, max_len, temp, enc=)      model/decoder.py:77-122
   model.decoder.net(x, mask=, enc=) -> (B, t, V)                          model/decoder.py:41-67
   create_model(config)                                                    model/ocr_model.py:113-130
-  model.load_state_dict(reference_state_dict)                             key layout: SURVEY.md 8a
+  model.state_dict() / model.load_state_dict(reference_state_dict)        key layout: SURVEY.md 8a
+
+The classes are nn.Modules whose parameters carry the reference's names -- including the aliases: ONE LayerNorm
+parameter pair is registered under ``layers.{s}.0`` for every sub-layer s of a stack (attention.py:200,221), so
+``state_dict()`` has the reference's keys (144 for the default dims) while ``parameters()`` counts each tensor once.
+The parameters are the host-visible master copy; the engine keeps its own re-laid-out copy (bf16 or fp32), refreshed
+lazily after ``load_state_dict`` (or ``model.sync_weights()`` after editing parameters in place).
 
 Differences that are deliberate and documented:
   * decoding is greedy by default (``decode='greedy'``: argmax; the reference samples with top-k /
     temperature / multinomial -- available as ``decode='sample'``);
-  * the decoder is KV-cached, so ``max_len`` must not exceed ``decoder.max_len`` (the reference would slide
-    its window, decoder.py:99-100) -> ValueError instead;
+  * the decoder is KV-cached; once the output outgrows ``decoder.max_len`` the reference slides its window
+    (decoder.py:99-100) and so does this build, by re-running the window through the cached path for every further
+    token (exact, slow: window-length engine steps per token);
   * errors are ValueError / RuntimeError, never ``assert``.
 There is no CPU path: tensors must live on the GPU and the HIP library must be built.
 """
 from __future__ import annotations
 
 import ctypes as C
+import math
 import re
 from typing import Dict, Optional
 
 import numpy as np
 import torch
+from torch import nn
 
-from . import _lib
+from . import _lib, ops
 from .config import Dims
 from .synth import state_dict_layout
 
 _DTYPES = {"fp32": _lib.TXO_F32, "f32": _lib.TXO_F32, "float32": _lib.TXO_F32,
            "bf16": _lib.TXO_BF16, "bfloat16": _lib.TXO_BF16}
-
 
 _LN_ALIAS = re.compile(r"\.layers\.(\d+)\.0\.(weight|bias)$")
 
@@ -41,20 +50,6 @@ _LN_ALIAS = re.compile(r"\.layers\.(\d+)\.0\.(weight|bias)$")
 def _is_ln_alias(key: str) -> bool:
     m = _LN_ALIAS.search(key)
     return bool(m) and int(m.group(1)) > 0
-
-
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
-
-
-def _dev_f32(t: torch.Tensor, name: str, device: Optional[int] = None) -> torch.Tensor:
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise ValueError(f"{name} must be a CUDA/HIP tensor (this engine has no CPU path)")
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name} must be float32, got {t.dtype}")
-    if device is not None and t.device.index != device:
-        raise ValueError(f"{name} lives on cuda:{t.device.index} but the engine was created on cuda:{device}")
-    return t.contiguous()
 
 
 class HipEngine:
@@ -71,16 +66,26 @@ class HipEngine:
         # tensors against it and runs with that device current
         self.device = torch.cuda.current_device()
         self.max_batch, self.max_tokens = max_batch, max_tokens or dims.n_pos
-        ch, cw = dims.canvas_hw
+        self.handle = None
+        self.loaded = False
+        self._provider = None            # callable -> reference-layout state dict (set by OCRModel)
+        self._stale = False              # the provider's weights are newer than the engine's copy
+        self._create()
+        self.id = ops.register_engine(self)
+
+    def _create(self) -> None:
+        d = self.dims
+        ch, cw = d.canvas_hw
         cfg = _lib.TxoConfig(
-            canvas_h=ch, canvas_w=cw, embed=1 if dims.embed == "hybrid" else 0,
-            in_channels=dims.in_channels, embed_dim=dims.embed_dim,
-            enc_heads=dims.enc_heads, enc_layers=dims.enc_layers, dec_heads=dims.dec_heads,
-            dec_layers=dims.dec_layers, enc_exp=dims.enc_exp, dec_exp=dims.dec_exp, vocab=dims.vocab,
-            max_len=dims.max_len, bos=dims.bos, eos=dims.eos, pad=dims.pad, dtype=_DTYPES[dtype],
-            max_batch=max_batch, max_tokens=self.max_tokens)
+            canvas_h=ch, canvas_w=cw, embed=1 if d.embed == "hybrid" else 0,
+            in_channels=d.in_channels, embed_dim=d.embed_dim,
+            enc_heads=d.enc_heads, enc_layers=d.enc_layers, dec_heads=d.dec_heads,
+            dec_layers=d.dec_layers, enc_exp=d.enc_exp, dec_exp=d.dec_exp, vocab=d.vocab,
+            max_len=d.max_len, bos=d.bos, eos=d.eos, pad=d.pad, dtype=_DTYPES[self.dtype],
+            max_batch=self.max_batch, max_tokens=self.max_tokens)
         h = C.c_void_p()
-        _lib.check(self.lib.txo_engine_create(C.byref(cfg), C.byref(h)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.txo_engine_create(C.byref(cfg), C.byref(h)))
         self.handle = h
         self.loaded = False
 
@@ -89,18 +94,20 @@ class HipEngine:
         if h:
             self.lib.txo_engine_destroy(h)
             self.handle = None
+        i = getattr(self, "id", None)
+        if i is not None:
+            ops.unregister_engine(i)
 
     # ---- weights -------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, "torch.Tensor | np.ndarray"], strict: bool = True) -> None:
-        """Accepts the reference OCRModel.state_dict() layout (aliased shared-LN keys included)."""
-        if self.loaded:
-            raise RuntimeError("weights already loaded into this engine; create a new model to load others")
+        """Upload a reference-layout state dict (aliased shared-LN keys included; aliases for s > 0 may be omitted).
+        Loading again replaces the engine (a handle's weights are immutable once finalized)."""
         want = {k: tuple(s) for k, s, _ in state_dict_layout(self.dims)}
-        # aliased LN keys for s > 0 may be omitted (same tensor as layers.0.0.*)
         missing = [k for k in want if k not in sd and not _is_ln_alias(k)]
         unexpected = [k for k in sd if k not in want]
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict: missing keys {sorted(set(missing))[:6]}, unexpected keys {unexpected[:6]}")
+        arrays = {}
         for k, v in sd.items():
             if k not in want:
                 continue
@@ -108,93 +115,65 @@ class HipEngine:
             a = np.ascontiguousarray(a, dtype=np.float32)
             if tuple(a.shape) != want[k]:
                 raise RuntimeError(f"load_state_dict: size mismatch for {k}: got {tuple(a.shape)}, expected {want[k]}")
-            shape = (C.c_int64 * a.ndim)(*a.shape)
-            _lib.check(self.lib.txo_engine_set_weight(self.handle, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
-        _lib.check(self.lib.txo_engine_finalize_weights(self.handle))
-        self.loaded = True
-
-    # ---- path ------------------------------------------------------------------------------------
-    def encode(self, img: torch.Tensor) -> torch.Tensor:
-        if img.ndim != 4:
-            raise ValueError("expected an image batch of shape (B, C, H, W)")
-        img = _dev_f32(img, "src", self.device)
-        B, Cc, H, W = img.shape
-        self.dims.check_image(Cc, H, W)
-        out = torch.empty((B, self.dims.n_tokens(H, W), self.dims.embed_dim), device=img.device, dtype=torch.float32)
+            arrays[k] = a
+        if self.loaded:
+            self.lib.txo_engine_destroy(self.handle)
+            self.handle = None
+            self._create()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.txo_encode(self.handle, img.data_ptr(), B, Cc, H, W, out.data_ptr(), _stream()))
-        return out
+            for k, a in arrays.items():
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                _lib.check(self.lib.txo_engine_set_weight(self.handle, k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim))
+            _lib.check(self.lib.txo_engine_finalize_weights(self.handle))
+        self.loaded = True
+        self._stale = False
+
+    def _ensure(self) -> None:
+        if (self._stale or not self.loaded) and self._provider is not None:
+            self.load_state_dict(self._provider())
+
+    # ---- path (every call goes through a torch.ops.texocr operator) -------------------------------------------------
+    def encode(self, img: torch.Tensor) -> torch.Tensor:
+        self._ensure()
+        return torch.ops.texocr.encode(img, self.id)
 
     def decode_begin(self, enc: torch.Tensor) -> None:
-        enc = _dev_f32(enc, "enc", self.device)
-        if enc.ndim != 3 or enc.shape[2] != self.dims.embed_dim:
-            raise ValueError(f"enc must be (B, N, {self.dims.embed_dim})")
-        self._enc_keepalive = enc
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.txo_decode_begin(self.handle, enc.data_ptr(), enc.shape[0], enc.shape[1], _stream()))
-        self._B = enc.shape[0]
+        self._ensure()
+        torch.ops.texocr.decode_begin(enc, self.id)
 
     def decode_step(self, t: int, tok_in: Optional[torch.Tensor] = None, want_logits: bool = True):
-        B = self._B
-        dev = self._enc_keepalive.device
-        logits = torch.empty((B, self.dims.vocab), device=dev, dtype=torch.float32) if want_logits else None
-        nxt = torch.empty((B,), device=dev, dtype=torch.int64)
-        if tok_in is not None:
-            if tok_in.dtype != torch.int64 or not tok_in.is_cuda or tok_in.shape != (B,):
-                raise ValueError("tok_in must be an int64 GPU tensor of shape (B,)")
-            if tok_in.device.index != self.device:
-                raise ValueError(f"tok_in lives on cuda:{tok_in.device.index} but the engine was created on cuda:{self.device}")
-            tok_in = tok_in.contiguous()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.txo_decode_step(self.handle, tok_in.data_ptr() if tok_in is not None else None, int(t),
-                                                logits.data_ptr() if want_logits else None, nxt.data_ptr(), _stream()))
-        return logits, nxt
+        logits, nxt = torch.ops.texocr.decode_step(tok_in, self.id, int(t), int(self._B), bool(want_logits))
+        return (logits if want_logits else None), nxt
 
     def generate(self, img: Optional[torch.Tensor], max_len: int, eos: Optional[int], enc: Optional[torch.Tensor] = None,
                  return_logits: bool = False):
         if (img is None) == (enc is None):
             raise ValueError("pass exactly one of img / enc")
-        src = _dev_f32(img if img is not None else enc, "src" if img is not None else "enc", self.device)
-        B = src.shape[0]
-        toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
-        logits = torch.empty((B, max_len, self.dims.vocab), device=src.device, dtype=torch.float32) if return_logits else None
-        n = C.c_int32(0)
+        self._ensure()
         e = -1 if eos is None else int(eos)
-        lp = logits.data_ptr() if return_logits else None
         if img is not None:
-            _, Cc, H, W = src.shape
-            self.dims.check_image(Cc, H, W)
-            rc = self.lib.txo_generate(self.handle, src.data_ptr(), B, Cc, H, W, int(max_len), e, toks.data_ptr(),
-                                       C.byref(n), lp, _stream())
+            toks, n, logits = torch.ops.texocr.generate(img, self.id, int(max_len), e, bool(return_logits))
         else:
-            rc = self.lib.txo_generate_from_enc(self.handle, src.data_ptr(), B, src.shape[1], int(max_len), e,
-                                                toks.data_ptr(), C.byref(n), lp, _stream())
-        _lib.check(rc)
-        self._B = B
-        self._enc_keepalive = src
-        toks = toks[:, :n.value]
-        return (toks, logits[:, :n.value]) if return_logits else toks
+            toks, n, logits = torch.ops.texocr.generate_from_enc(enc, self.id, int(max_len), e, bool(return_logits))
+        n = int(n.item())
+        toks = toks[:, :n]
+        return (toks, logits[:, :n]) if return_logits else toks
 
     def generate_beam(self, img: torch.Tensor, beams: int, max_len: int, eos: Optional[int], return_beams: bool = False):
         """Beam search (build extension; the reference has none).  Returns the best beam's tokens (B, n), or with
         return_beams=True (tokens (B, beams, n), scores (B, beams)) sorted best first."""
-        src = _dev_f32(img, "src", self.device)
-        B, Cc, H, W = src.shape
-        self.dims.check_image(Cc, H, W)
-        toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
-        scores = torch.empty((B, beams), device=src.device, dtype=torch.float32)
-        allt = torch.empty((B * beams, max_len), device=src.device, dtype=torch.int64) if return_beams else None
-        n = C.c_int32(0)
-        _lib.check(self.lib.txo_generate_beam(self.handle, src.data_ptr(), B, Cc, H, W, int(beams), int(max_len),
-                                              -1 if eos is None else int(eos), toks.data_ptr(), scores.data_ptr(),
-                                              allt.data_ptr() if return_beams else None, C.byref(n), _stream()))
+        self._ensure()
+        toks, scores, allt, n = torch.ops.texocr.generate_beam(img, self.id, int(beams), int(max_len),
+                                                              -1 if eos is None else int(eos), bool(return_beams))
+        n = int(n.item())
         if return_beams:
-            return allt[:, :n.value].reshape(B, beams, n.value), scores
-        return toks[:, :n.value]
+            return allt[:, :n].reshape(img.shape[0], beams, n), scores
+        return toks[:, :n]
 
     def set_sampling(self, on: bool, temp: float = 1.0, seed: int = 0, threshold: float = 0.9) -> None:
         """on=True: the reference sampler (top-k with k = int((1 - threshold) * vocab), utils.py:85-91 -- 99 for
         vocab 1000 because of float rounding -- then softmax(/temp) and one multinomial draw, decoder.py:104-108)."""
+        self._ensure()
         k = int((1 - threshold) * self.dims.vocab)
         _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
 
@@ -207,6 +186,7 @@ class HipEngine:
     # profiling hooks used by bench.py
     def profile(self, on) -> None:
         """0/False off, 1/True full (markers around every encode and step), 2 cross-attention dispatch events only."""
+        self._ensure()
         _lib.check(self.lib.txo_profile_enable(self.handle, int(on)))
 
     def profile_read(self, kind: int):
@@ -216,32 +196,80 @@ class HipEngine:
 
 
 # --------------------------------------------------------------------------------------------------
+# parameters in the reference's module tree
+# --------------------------------------------------------------------------------------------------
+class _Node(nn.Module):
+    """A name-only container: the reference's module tree is mirrored for its parameter NAMES."""
+
+
+def _attach(root: nn.Module, dotted: str, p: nn.Parameter) -> None:
+    parts = dotted.split(".")
+    m = root
+    for name in parts[:-1]:
+        if name not in m._modules:
+            m.add_module(name, _Node())
+        m = m._modules[name]
+    m.register_parameter(parts[-1], p)
+
+
+_NORM_KEY = re.compile(r"(layers\.\d+\.0|\.norm|stem\.1|\.block(_list)?\.[135])\.(weight|bias)$")
+
+
+def _default_init(key: str, shape, fan_in_of: Dict[str, int], gen: torch.Generator) -> torch.Tensor:
+    """torch's default initialisers of the reference's layers (values only matter until load_state_dict)."""
+    leaf = key.rsplit(".", 1)[-1]
+    if key.endswith(("cls_token", "pos_embed")):
+        return torch.zeros(shape)                                            # encoder.py:106-107 (never initialised there)
+    if "embedding" in key:
+        return torch.randn(shape, generator=gen)                             # nn.Embedding
+    if _NORM_KEY.search(key):
+        return torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+    fan_in = fan_in_of.get(key[: -len(leaf)] + "weight", 1)
+    bound = 1.0 / math.sqrt(max(fan_in, 1))                                  # kaiming_uniform(a=sqrt(5)) and the bias bound
+    return (torch.rand(shape, generator=gen) * 2 - 1) * bound
+
+
+def _build_params(root: nn.Module, dims: Dims, prefix: str, shared: Dict[str, nn.Parameter], device) -> None:
+    layout = state_dict_layout(dims)
+    fan_in = {k: int(np.prod(s[1:])) for k, s, _ in layout if len(s) > 1}
+    gen = torch.Generator().manual_seed(0)
+    for key, shape, canon in layout:
+        if not key.startswith(prefix):
+            continue
+        if canon not in shared:
+            shared[canon] = nn.Parameter(_default_init(canon, shape, fan_in, gen).to(device), requires_grad=False)
+        _attach(root, key[len(prefix):], shared[canon])
+
+
+# --------------------------------------------------------------------------------------------------
 # reference-shaped facades
 # --------------------------------------------------------------------------------------------------
-class VisionEncoder:
+class VisionEncoder(nn.Module):
     """model.encoder: callable (B,C,H,W) -> (B, N, D); CLS token at index 0 (encoder.py:128-152)."""
 
-    def __init__(self, engine: HipEngine):
+    def __init__(self, engine: HipEngine, _shared: Optional[dict] = None):
+        super().__init__()
         self._engine = engine
         d = engine.dims
         self.height, self.width = d.canvas_hw
         self.patch_size = d.patch
+        _build_params(self, d, "encoder.", _shared if _shared is not None else {}, torch.device("cuda", engine.device))
 
-    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self._engine.encode(x)
 
-    forward = __call__
 
-
-class Transformer:
+class Transformer(nn.Module):
     """model.decoder.net: (B,t) int64 tokens -> (B,t,V) logits over the whole prefix (decoder.py:41-67).
     Implemented as t KV-cached steps, which equals the reference's full-prefix causal forward."""
 
-    def __init__(self, engine: HipEngine):
+    def __init__(self, engine: HipEngine, _shared: Optional[dict] = None):
+        super().__init__()
         self._engine = engine
         self.max_len = engine.dims.max_len
+        _build_params(self, engine.dims, "decoder.net.", _shared if _shared is not None else {}, torch.device("cuda", engine.device))
 
-    def __call__(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, enc: Optional[torch.Tensor] = None, **kw):
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None, enc: Optional[torch.Tensor] = None, **kw):
         if kw:
             raise ValueError(f"unsupported arguments for the inference path: {sorted(kw)}")
         if enc is None:
@@ -255,19 +283,26 @@ class Transformer:
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
         eng.decode_begin(enc)
-        out = [eng.decode_step(t, x[:, t].contiguous())[0] for t in range(x.shape[1])]
-        return torch.stack(out, dim=1)
+        out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
+        xt = x.t().contiguous()                                   # one contiguous token row per position
+        for t in range(x.shape[1]):
+            out[:, t] = eng.decode_step(t, xt[t])[0]
+        return out
 
-    forward = __call__
 
-
-class AutoRegressiveDecoder:
+class AutoRegressiveDecoder(nn.Module):
     """model.decoder (decoder.py:70-122)."""
 
-    def __init__(self, engine: HipEngine):
+    def __init__(self, engine: HipEngine, _shared: Optional[dict] = None):
+        super().__init__()
         self._engine = engine
-        self.net = Transformer(engine)
+        self.net = Transformer(engine, _shared)
         self.max_len = self.net.max_len
+        self._resample = None
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("AutoRegressiveDecoder.forward is the training loss (decoder.py:124-145); this engine "
+                                  "implements the generate() inference path only")
 
     @torch.no_grad()
     def generate(self, start_tokens: torch.Tensor, eos_tok: Optional[int], max_len: int, temp: float = 1.0,
@@ -286,16 +321,16 @@ class AutoRegressiveDecoder:
         squeeze = start_tokens.ndim == 1
         st = start_tokens[None, :] if squeeze else start_tokens                  # decoder.py:88
         B, T0 = st.shape
-        if T0 + max_len - 1 > self.max_len:
-            raise ValueError(f"start length {T0} + max_len {max_len} exceeds decoder.max_len {self.max_len}: the "
-                             "reference would slide its window (decoder.py:99-100); the KV-cached engine refuses")
         eng = self._engine
+        self._resample = None
         if decode == "sample":
             if seed is None:
                 seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2**62, (1,)).item())
             eng.set_sampling(True, temp=temp, seed=seed)
+            self._resample = (temp, seed)
         try:
-            if T0 == 1 and bool((st == eng.dims.bos).all()):
+            fits = T0 + max_len - 1 <= self.max_len
+            if fits and T0 == 1 and bool((st == eng.dims.bos).all()):
                 out = eng.generate(None, max_len, eos_tok, enc=enc)
             else:
                 out = self._generate_stepwise(st, eos_tok, max_len, enc)
@@ -305,47 +340,89 @@ class AutoRegressiveDecoder:
         return out.squeeze(0) if squeeze else out
 
     def _generate_stepwise(self, st, eos_tok, max_len, enc):
-        """General form (arbitrary start prefix): one engine step per position with the reference's per-step
-        host-side eos check (decoder.py:115-116); the engine picks the token (argmax or its sampler)."""
+        """General form (arbitrary start prefix, any max_len): one engine step per position with the reference's per-step
+        host-side eos check (decoder.py:115-116); the engine picks the token (argmax or its sampler).
+
+        While the output fits the positional table the KV cache is extended by one position per token.  Beyond it the
+        reference feeds ``output[:, -max_len:]`` through the whole decoder with positions re-indexed from 0
+        (decoder.py:99-100): no cached key survives that shift, so every further token re-runs its window through the
+        cached path (max_len engine steps per token).  Exact and slow -- the reference is as slow there."""
         eng = self._engine
         st = st.to(enc.device)
         B, T0 = st.shape
+        L = self.max_len
         eng.decode_begin(enc)
-        for t in range(T0 - 1):
-            eng.decode_step(t, st[:, t].contiguous(), want_logits=False)
-        tok = st[:, T0 - 1].contiguous()
         output = st
+        valid = 0                                                  # positions of the CURRENT window held by the cache
         for i in range(max_len):
-            _, tok = eng.decode_step(T0 - 1 + i, tok, want_logits=False)
+            window = output[:, -L:]                                # decoder.py:99-100
+            n = window.shape[1]
+            if output.shape[1] > L:
+                valid = 0                                          # every position shifted: nothing cached is reusable
+            wt = window.t().contiguous()
+            for p in range(valid, n - 1):
+                eng.decode_step(p, wt[p], want_logits=False)
+            if self._resample is not None and output.shape[1] > L:
+                # the device sampler draws from a counter RNG keyed by (seed, row, position); once the window slides the
+                # position stays at L - 1, so the seed advances with the token index instead
+                eng.set_sampling(True, temp=self._resample[0], seed=self._resample[1] + i)
+            _, tok = eng.decode_step(n - 1, wt[n - 1], want_logits=False)
+            valid = n
             output = torch.cat((output, tok[:, None]), dim=-1)
             if eos_tok is not None and bool((output == eos_tok).any(dim=1).all()):
                 break
         return output[:, T0:]
 
 
-class OCRModel:
+class OCRModel(nn.Module):
     """TeXOCR model for image-to-LaTeX conversion -- inference surface (ocr_model.py:14-66)."""
 
     def __init__(self, encoder: VisionEncoder, decoder: AutoRegressiveDecoder, bos_token: int, eos_token: int,
                  trg_pad_idx: int, device: torch.device):
+        super().__init__()
         if encoder._engine is not decoder._engine:
             raise ValueError("encoder and decoder must share one engine")
         self.encoder, self.decoder = encoder, decoder
         self.bos_token, self.eos_token, self.trg_pad_idx = bos_token, eos_token, trg_pad_idx
         self.device = device
         self._engine = encoder._engine
-        self.training = False
+        self._engine._provider = self._export_weights
+        self._engine._stale = True
+        self.eval()
 
-    def eval(self):
+    # ---- weights: the reference's state_dict layout, aliases included ----
+    def _export_weights(self) -> Dict[str, torch.Tensor]:
+        return dict(self.state_dict())
+
+    def sync_weights(self) -> "OCRModel":
+        """Re-upload the parameters to the engine at the next call (after editing them in place)."""
+        self._engine._stale = True
         return self
 
-    def to(self, device):
-        if torch.device(device).type != "cuda":
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """nn.Module.load_state_dict for the reference's key layout.  Accepts tensors or numpy arrays; the aliased
+        shared-LayerNorm keys layers.{s}.0.* (s > 0) may be omitted, and when given must equal layers.0.0.* -- the
+        reference holds ONE LayerNorm per stack (attention.py:200,221)."""
+        sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in state_dict.items()}
+        own = self.state_dict()
+        for k in own:
+            if _is_ln_alias(k):
+                base = _LN_ALIAS.sub(lambda m: f".layers.0.0.{m.group(2)}", k)
+                if k in sd and base in sd and not torch.equal(sd[k].float().cpu(), sd[base].float().cpu()):
+                    raise ValueError(f"{k} differs from {base}: the reference shares ONE LayerNorm per stack")
+                if k not in sd and base in sd:
+                    sd[k] = sd[base]
+        for k, v in sd.items():
+            if k in own and tuple(v.shape) != tuple(own[k].shape):
+                raise RuntimeError(f"load_state_dict: size mismatch for {k}: got {tuple(v.shape)}, expected {tuple(own[k].shape)}")
+        res = super().load_state_dict(sd, strict=strict)
+        self._engine._stale = True
+        return res
+
+    def to(self, *args, **kwargs):
+        dev = kwargs.get("device", args[0] if args else None)
+        if dev is not None and not isinstance(dev, torch.dtype) and torch.device(dev).type != "cuda":
             raise ValueError("this model only runs on the GPU")
-        return self
-
-    def load_state_dict(self, state_dict, strict: bool = True):
-        self._engine.load_state_dict(state_dict, strict=strict)
         return self
 
     @torch.no_grad()
@@ -353,12 +430,13 @@ class OCRModel:
                  generator: Optional[torch.Generator] = None, seed: Optional[int] = None, return_logits: bool = False,
                  beam: int = 0, return_beams: bool = False):
         if beam:                                           # build extension (BASELINE config 5); engine max_batch >= B * beam
-            return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
-        if decode == "greedy" and self.bos_token == self._engine.dims.bos:
             if max_len > self.decoder.max_len:
-                raise ValueError(f"max_len {max_len} exceeds decoder.max_len {self.decoder.max_len}: the reference "
-                                 "would slide its window (decoder.py:99-100); the KV-cached engine refuses")
+                raise ValueError(f"beam search needs max_len <= decoder.max_len ({self.decoder.max_len})")
+            return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
+        if decode == "greedy" and self.bos_token == self._engine.dims.bos and max_len <= self.decoder.max_len:
             return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
+        if return_logits:
+            raise ValueError("return_logits needs greedy decoding inside the positional table (max_len <= decoder.max_len)")
         enc = self.encoder(src)
         start = torch.full((src.shape[0], 1), self.bos_token, dtype=torch.int64, device=src.device)   # ocr_model.py:57
         return self.decoder.generate(start_tokens=start, eos_tok=self.eos_token, max_len=max_len, temp=temp,
@@ -368,19 +446,22 @@ class OCRModel:
         raise NotImplementedError("OCRModel.forward is the training loss (ocr_model.py:38-44); this engine "
                                   "implements the generate() inference path only")
 
-    __call__ = forward
+
+def _assemble(dims: Dims, dtype: str, max_batch: int, max_tokens: int, device: torch.device) -> OCRModel:
+    eng = HipEngine(dims, dtype=dtype, max_batch=max_batch, max_tokens=max_tokens)
+    shared: Dict[str, nn.Parameter] = {}
+    return OCRModel(VisionEncoder(eng, shared), AutoRegressiveDecoder(eng, shared), dims.bos, dims.eos, dims.pad, device)
 
 
 def create_model(config: dict, dtype: str = "fp32", max_batch: int = 64, max_tokens: int = 0) -> OCRModel:
-    """create_model(config) (ocr_model.py:113-130) with the PatchEmbedding front end."""
+    """create_model(config) (ocr_model.py:113-130).  As in the reference the model comes back with default-initialised
+    parameters; load_state_dict replaces them."""
     dims = Dims.from_config(config)
-    eng = HipEngine(dims, dtype=dtype, max_batch=max_batch, max_tokens=max_tokens)
     device = torch.device(config.get("device", "cuda"))
     if device.type != "cuda":
         device = torch.device("cuda")
-    return OCRModel(VisionEncoder(eng), AutoRegressiveDecoder(eng), dims.bos, dims.eos, dims.pad, device)
+    return _assemble(dims, dtype, max_batch, max_tokens, device)
 
 
 def model_from_dims(dims: Dims, dtype: str = "fp32", max_batch: int = 64, max_tokens: int = 0) -> OCRModel:
-    eng = HipEngine(dims, dtype=dtype, max_batch=max_batch, max_tokens=max_tokens)
-    return OCRModel(VisionEncoder(eng), AutoRegressiveDecoder(eng), dims.bos, dims.eos, dims.pad, torch.device("cuda"))
+    return _assemble(dims, dtype, max_batch, max_tokens, torch.device("cuda"))

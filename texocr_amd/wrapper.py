@@ -6,7 +6,9 @@ Differences from the reference, all on the host side of the path:
     Grayscale(1) -> Invert) WITHOUT the train-time ``RandomAffine``; torchvision is not needed;
   * images whose sides are not multiples of 16 are padded (bottom/right, background = 0 after inversion); the
     reference relies on the dataset renderer having padded them already (render_data.py:81-92);
-  * ``decode`` selects the reference's sampler ('sample', its default, temp 0.3) or greedy.
+  * ``decode`` selects the reference's sampler ('sample', its default, temp 0.3) or greedy;
+  * ``max_len`` is passed through unchanged (default 350, ocr_model.py:94): beyond the positional table the decoder
+    slides its window as the reference does.
 """
 from __future__ import annotations
 
@@ -57,7 +59,8 @@ class TeXOCRWrapper:
         if self.dims.in_channels != 1:
             x = x.expand(self.dims.in_channels, -1, -1)
         x = x[None].contiguous().cuda()
-        max_len = min(max_len, self.model.decoder.max_len)
+        # max_len may exceed the positional table (the reference's default 350 does for short tables): the model then
+        # slides its window exactly as the reference does (decoder.py:99-100), at window-length engine steps per token
         toks = self.model.generate(x, max_len=max_len, temp=temp, decode=decode, seed=seed)
         out_tokens = toks.squeeze(0).tolist()[:-1]                                   # ocr_model.py:104 (drops the EOS)
         return out_tokens, process_output(self.tokenizer.decode(out_tokens))         # :105-108
