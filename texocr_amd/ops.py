@@ -44,11 +44,13 @@ def unregister_engine(i: int) -> None:
     _ENGINES.pop(i, None)
 
 
-def _eng(i: int):
+def _eng(i: int, ready: bool = False):
     r = _ENGINES.get(int(i))
     e = r() if r is not None else None
     if e is None:
         raise RuntimeError(f"texocr: no live engine with id {i}")
+    if ready and hasattr(e, "_ensure"):
+        e._ensure()                      # upload the owning module's parameters if they changed since the last call
     return e
 
 
@@ -73,7 +75,7 @@ def _ptr(t: Optional[torch.Tensor]):
 # ---------------------------------------------------------------------------------------------------------------
 @custom_op("texocr::encode", mutates_args=())
 def encode(img: torch.Tensor, engine: int) -> torch.Tensor:
-    e = _eng(engine)
+    e = _eng(engine, ready=True)
     if img.ndim != 4:
         raise ValueError("expected an image batch of shape (B, C, H, W)")
     img = _f32_dev(img, "src", e)
@@ -94,7 +96,7 @@ def _(img, engine):
 
 @custom_op("texocr::decode_begin", mutates_args=())
 def decode_begin(enc: torch.Tensor, engine: int) -> None:
-    e = _eng(engine)
+    e = _eng(engine, ready=True)
     enc = _f32_dev(enc, "enc", e)
     if enc.ndim != 3 or enc.shape[2] != e.dims.embed_dim:
         raise ValueError(f"enc must be (B, N, {e.dims.embed_dim})")
@@ -149,7 +151,7 @@ def _gen_outputs(src, e, max_len, want_logits):
 def generate(img: torch.Tensor, engine: int, max_len: int, eos: int, want_logits: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Greedy OCRModel.generate: (tokens (B, max_len) of which the first n are valid, n as an int64 CPU tensor of shape (1,),
     logits (B, max_len, V) or (0, max_len, V)).  eos < 0: no eos test (eos_tok=None)."""
-    e = _eng(engine)
+    e = _eng(engine, ready=True)
     if img.ndim != 4:
         raise ValueError("expected an image batch of shape (B, C, H, W)")
     img = _f32_dev(img, "src", e)
@@ -174,7 +176,7 @@ def _(img, engine, max_len, eos, want_logits):
 
 @custom_op("texocr::generate_from_enc", mutates_args=())
 def generate_from_enc(enc: torch.Tensor, engine: int, max_len: int, eos: int, want_logits: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    e = _eng(engine)
+    e = _eng(engine, ready=True)
     enc = _f32_dev(enc, "enc", e)
     if enc.ndim != 3 or enc.shape[2] != e.dims.embed_dim:
         raise ValueError(f"enc must be (B, N, {e.dims.embed_dim})")
@@ -199,7 +201,7 @@ def _(enc, engine, max_len, eos, want_logits):
 def generate_beam(img: torch.Tensor, engine: int, beams: int, max_len: int, eos: int, want_all: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Beam search (build extension): (best tokens (B, max_len), scores (B, beams), all beams (B*beams, max_len) or (0, max_len),
     n as an int64 CPU tensor)."""
-    e = _eng(engine)
+    e = _eng(engine, ready=True)
     img = _f32_dev(img, "src", e)
     B, Cc, H, W = img.shape
     e.dims.check_image(Cc, H, W)
