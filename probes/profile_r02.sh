@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-2 evidence run (GPU box, repository root): the default bench line, the same under torch.distributed.run with one rank
+# (RCCL all-gather inside the timed region), rocprofv3 --kernel-trace --stats summaries for batch 64 / batch 256 / config 4,
+# and the PMC traffic passes for batch 64 and 256.  Outputs under gpurun_out/; the summaries are copied to profiles/ by hand.
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out
+python3 bench.py > $O/r02_bench_default.json 2> $O/r02_bench_default.err
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 2 \
+    --no-extras --no-cpu-baseline > $O/r02_bench_torchrun1.json 2> $O/r02_bench_torchrun1.err
+FL="--steps 4 --warmup 1 --settle-seconds 0 --no-extras --no-cpu-baseline --no-roofline"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b64 -- python3 bench.py $FL > $O/prof_r02_b64.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b256 -- python3 bench.py $FL --batch 256 > $O/prof_r02_b256.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_cfg4 -- python3 bench.py $FL --batch 256 --model cfg4 --steps 2 > $O/prof_r02_cfg4.log 2>&1
+bash probes/collect_pmc.sh bf16 64
+bash probes/collect_pmc.sh bf16 256
+python3 probes/pmc_summary.py $O/pmc_bf16_b64 bf16 64 > $O/r02_pmc_bf16_b64.json
+python3 probes/pmc_summary.py $O/pmc_bf16_b256 bf16 256 > $O/r02_pmc_bf16_b256.json
+for d in b64 b256 cfg4; do f=$(find $O/prof_r02_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r02_${d}_bf16_kernel_stats.csv; done
+ls -la $O | tail -20

@@ -273,9 +273,12 @@ def test_bf16_mode_logits_error_bounded():
     ref_top = torch.from_numpy(g["top5_vals"][:, :64])
     got_top = torch.gather(tf, 2, torch.from_numpy(g["top5_ids"][:, :64].astype(np.int64)))
     err = float((got_top - ref_top).abs().max())
-    assert err < 0.25, err                                   # logits span about [-3, 3]
     agree = float((tf.argmax(-1) == toks[:, :64].cpu()).float().mean())
-    assert agree > 0.9, agree                                # teacher-forced top-1 agreement
+    print(f"cfg1 bf16 vs reference fixture, teacher-forced 4x64: max |dlogit| over the reference's top-5 {err:.4f}, top-1 agreement {agree:.4f}")
+    # measured on MI355X: max |dlogit| ~0.04 on logits spanning about [-3, 3], agreement ~0.98 (disagreements sit on the
+    # thinnest margins of this random-weight model: the fixture's smallest top-1/top-2 margin is 1e-4)
+    assert err < 0.1, err
+    assert agree > 0.95, agree                               # teacher-forced top-1 agreement
 
 
 # ------------------------------------------------------------------------------------------------
@@ -769,7 +772,7 @@ def test_cfg4_vit_base_golden():
     agree = float((tb.cpu().numpy() == g["tokens"]).mean())
     lerr = float(np.abs(lb.cpu().numpy() - g["step_logits"]).max())
     print(f"cfg4 bf16 vs reference: free-running token agreement {agree:.3f} over 2x8, max |dlogit| {lerr:.3f} (fixture margin >= 0.032)")
-    assert lerr < 0.5 and agree >= 0.5
+    assert lerr < 0.15 and agree >= 0.8
 
 
 def test_cfg4_full_size_b256():
@@ -867,7 +870,7 @@ def test_cfg2_full_size_bf16():
     first = float((t1[:, 0] == tf_[:, 0]).float().mean())
     print(f"cfg2 bf16 vs fp32 engine, B=64 x 64 steps: teacher-forced top-1 agreement {agree:.4f}, max |dlogit| {err:.3f}, "
           f"free-running first-token agreement {first:.3f}")
-    assert agree > 0.9 and err < 0.3
+    assert agree > 0.95 and err < 0.1
 
 
 def test_torch_free_c_program_on_the_c_abi(tmp_path):
