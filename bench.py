@@ -228,7 +228,7 @@ def main():
         return toks
 
     if not a.no_roofline and rank == 0:
-        eng.profile(2); eng.profile(0)          # creates the event pool now, outside the timed region
+        eng.profile(3); eng.profile(2); eng.profile(0)          # creates the event pools now, outside the timed region
     t_settle = time.perf_counter()
     while time.perf_counter() - t_settle < a.settle_seconds:      # local work only: ranks may run different counts
         model.generate(imgs[0], a.max_len)
@@ -236,6 +236,7 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    persistent = eng.query(0) == 1                  # which decode path generate() takes for this batch / dtype (engine.hip: persist_usable)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -243,10 +244,11 @@ def main():
     lat = []
     for i in range(a.steps):
         if i == a.steps - 1 and not a.no_roofline and rank == 0:
-            # every fourth cross-attention dispatch of the LAST timed step carries HIP events (bound to the dispatch, no extra
-            # commands on the stream).  An event-carrying launch costs ~2 us of wall time (9 % of a step with all of them
-            # instrumented), which `value` must not pay K times.
-            eng.profile(2)
+            # the LAST timed step carries HIP events bound to its dominant dispatch(es), nothing else on the stream:
+            #   persistent decode (the default at this batch in bf16): the one launch of the whole decode loop;
+            #   launch-per-stage decode: every fourth cross-attention dispatch (an event-carrying launch costs ~2 us of wall
+            #   time: 9 % of a step with all of them instrumented, which `value` must not pay K times).
+            eng.profile(3 if persistent else 2)
         s0 = time.perf_counter()
         out = step(i)
         torch.cuda.synchronize()
@@ -280,43 +282,82 @@ def main():
                                     else "BASELINE configs[3]: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h), PatchEmbedding C=3, ") +
                                    f"batch {a.batch}/GPU, {a.height}x{a.width}, greedy max_len={a.max_len}",
                        "global_batch": a.batch * world, "tokens_per_image": N,
-                       "parallelism": f"dp{world} (images sharded, " + ("one RCCL all-gather of token ids per step" if dist_on else "single process, no collective") + ")"},
+                       "parallelism": f"dp{world} (images sharded, " + ("one RCCL all-gather of token ids per step" if dist_on else "single process, no collective") + ")",
+                       "decode_path": "persistent launch (csrc/persist.h)" if persistent else "one launch per stage"},
         }
         if not a.no_roofline:
-            ms_live, n_live = eng.profile_read(0)          # measured over the timed region above
-            eng.profile(True)                               # separate pass: encoder and whole-step spans (marker commands)
-            model.generate(imgs[0], a.max_len)
-            torch.cuda.synchronize()
-            ms, n = eng.profile_read(0)
-            ems, en = eng.profile_read(1)
-            sms, sn = eng.profile_read(2)
-            eng.profile(False)
-            algo = a.batch * dims.dec_heads * 2 * N * 64 * esz
-            traffic, traffic_source = None, None   # PMC bytes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), separate rocprofv3 passes
+            Ld, heads = dims.dec_layers, dims.dec_heads
+            algo_cross = a.batch * heads * 2 * N * 64 * esz                 # one cross-attention launch / stage: K and V panels once
+            mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3              # dense TFLOP/s, MI355X_MICROARCH.md
+            def pmc(kind):
+                for rnd in ("r02", "r01"):
+                    fn = os.path.join("profiles", f"{rnd}_pmc_{kind}{a.dtype}_b{a.batch}.json")
+                    try:
+                        pm = json.load(open(os.path.join(ROOT, fn)))["traffic"]
+                        if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N, "max_len": a.max_len}:
+                            return pm["traffic_bytes"], fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
+                    except Exception:
+                        pass
+                return None, None
+            if persistent:
+                ms_live, n_live = eng.profile_read(3)                       # the persistent launch of the last timed step
+                # K/V bytes the decode loop has to read: per position, every layer, the cross panels (2*N rows) and the
+                # self-attention history (2*(t+1) rows) of every (image, head), 64 elements each
+                rows = sum(2 * N + 2 * (t + 1) for t in range(a.max_len))
+                algo = a.batch * heads * 64 * esz * Ld * rows
+                ach = algo / (ms_live * 1e-3) / 1e9 if ms_live > 0 else 0.0
+                traffic, tsrc = pmc("persist_")
+                result["roofline"] = {
+                    "kernel": "decode_persist_kernel (the whole 256-position decode loop as one launch; texocr_amd/csrc/persist.h)",
+                    "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                    "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo,
+                    "algorithmic_bytes": "cross-attention K/V panels + self-attention history read once per position and layer "
+                                         "(weights and activations stay in L2 / Infinity Cache)",
+                    "avg_launch_us": round(ms_live * 1e3, 1), "launches_timed": n_live,
+                    "timed_over": "the last of the K timed steps (HIP events bound to the dispatch)",
+                    "us_per_position": round(ms_live * 1e3 / a.max_len, 2)}
+            # the launch-per-stage path (what runs at other batch sizes / in fp32 / when profiling): cross-attention kernel by
+            # dispatch-bound events of one generate, then encoder and whole-step spans by marker events
+            os.environ["TXO_PERSIST"] = "0"
+            try:
+                eng.profile(2)
+                model.generate(imgs[0], a.max_len)
+                torch.cuda.synchronize()
+                ms_x, n_x = eng.profile_read(0)
+                eng.profile(True)
+                model.generate(imgs[0], a.max_len)
+                torch.cuda.synchronize()
+                ems, en = eng.profile_read(1)
+                sms, sn = eng.profile_read(2)
+                eng.profile(False)
+            finally:
+                os.environ.pop("TXO_PERSIST")
+            traffic, tsrc = None, None
             for rnd in ("r02", "r01"):
                 fn = os.path.join("profiles", f"{rnd}_pmc_{a.dtype}_b{a.batch}.json")
                 try:
                     pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]
                     if pm["config"] == {"batch": a.batch, "dtype": a.dtype, "tokens": N}:
-                        traffic, traffic_source = pm["traffic_bytes"], fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
+                        traffic, tsrc = pm["traffic_bytes"], fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
                         break
                 except Exception:
                     pass
-            mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3          # dense TFLOP/s, MI355X_MICROARCH.md
+            ach_x = algo_cross / (ms_x * 1e-3) / 1e9 if ms_x > 0 else 0.0
+            cross = {"kernel": "dec_attn_kernel (decode-step cross-attention, launch-per-stage path)", "bound": "hbm",
+                     "achieved": round(ach_x, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_x / 8000.0, 4),
+                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo_cross,
+                     "avg_launch_us": round(ms_x * 1e3, 2), "launches_timed": n_x,
+                     "timed_over": "a separate generate() with TXO_PERSIST=0 (dispatch-bound HIP events on every fourth launch)",
+                     "decode_step_us_with_events": round(sms * 1e3, 1)}
             enc_tf = enc_flop(dims, a.batch, N) / (ems * 1e-3) / 1e12 if ems > 0 else 0.0
-            ms_pass, n_pass = ms, n
-            if n_live > 0:
-                ms, n = ms_live, n_live
-            ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            result["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm",
-                                  "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                                  "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo,
-                                  "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n,
-                                  "timed_over": "the last of the K timed steps (dispatch-bound HIP events)" if n_live > 0 else "separate profiled pass",
-                                  "avg_launch_us_profiled_pass": round(ms_pass * 1e3, 2),
-                                  "encoder_ms": round(ems, 3), "decode_step_us_with_events": round(sms * 1e3, 1),
-                                  "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
-                                                   "frac": round(enc_tf / mfma_peak, 4)}}
+            enc = {"encoder_ms": round(ems, 3), "encoder_mfma": {"achieved": round(enc_tf, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                                                                 "frac": round(enc_tf / mfma_peak, 4)}}
+            if persistent:
+                result["roofline"].update(enc)
+                result["roofline_cross_attention_kernel"] = cross
+            else:
+                cross.update(enc)
+                result["roofline"] = cross
         if world == 1 and not a.no_extras:
             del model, eng
             torch.cuda.empty_cache()

@@ -121,7 +121,9 @@ int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint
  * 1 = encoder (whole txo_encode), 2 = whole decode step.
  * on = 1: everything above (adds marker commands around every encode and step -- use in a separate pass); on = 2: only every
  * fourth cross-attention dispatch carries events (bound to the dispatch, no extra commands; safe inside a timed region; samples are
- * kept for the first 16 generate() calls after enabling); on = 0: off. */
+ * kept for the first 16 generate() calls after enabling); on = 3: the persistent decode launch carries events (kind 3 =
+ * its duration; the launch-per-stage path is not instrumented in this mode, and modes 1 / 2 make generate() take that path);
+ * on = 0: off. */
 int txo_profile_enable(txo_engine* e, int32_t on);
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count);
 

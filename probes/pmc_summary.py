@@ -12,7 +12,8 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             if r["Counter_Name"] == counter:
                 acc[r["Kernel_Name"].split("(")[0]][counter].append(float(r["Counter_Value"]))
 B, heads, N, esz = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), 8, 589, (2 if dtype == "bf16" else 4)
-kernels, cross = {}, None
+max_len = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+kernels, cross, persist = {}, None, None
 for name, c in sorted(acc.items()):
     if "txo::" not in name:
         continue
@@ -22,7 +23,22 @@ for name, c in sorted(acc.items()):
         e["algorithmic_bytes_per_launch"] = B * heads * 2 * N * 64 * esz
         e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
         cross = (name, e)
+    if "decode_persist_kernel" in name:                                    # the whole decode loop as one launch
+        rows = sum(2 * N + 2 * (t + 1) for t in range(max_len))
+        e["algorithmic_bytes_per_launch"] = B * heads * 64 * esz * 4 * rows     # 4 decoder layers
+        e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
+        persist = (name, e)
     kernels[name] = e
+if persist is not None:
+    print(json.dumps({"note": "rocprofv3 --pmc <counter> --kernel-trace, separate passes (probes/collect_pmc.sh <dtype> <batch> <max_len>): the "
+                              f"persistent decode launch, B={B}, {dtype}, 3x224x672, {max_len} positions.  hbm_read_bytes = 2 * FETCH_SIZE * 1024 "
+                              "(gfx950 correction for 16-byte-per-lane streams; the launch also reads weights and rows through L2 with narrower "
+                              "accesses, for which the factor is uncalibrated).",
+                      "traffic": {"config": {"batch": B, "dtype": dtype, "tokens": N, "max_len": max_len}, "kernel": persist[0],
+                                  "traffic_bytes": persist[1]["hbm_bytes_per_launch_corrected"],
+                                  "algorithmic_bytes": persist[1]["algorithmic_bytes_per_launch"]},
+                      "kernels": kernels}, indent=1, sort_keys=True))
+    sys.exit(0)
 out = {"note": "rocprofv3 --pmc <counter> --kernel-trace, separate passes (probes/collect_pmc.sh), bench.py --steps 1 --max-len 24 "
                f"(B={B}, {dtype}, 3x224x672). FETCH_SIZE/WRITE_SIZE are in KB; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950 correction).",
        "cross_attention_traffic": {"config": {"batch": B, "dtype": dtype, "tokens": N}, "kernel": cross[0],

@@ -672,18 +672,18 @@ def test_wide_decoder_large_batch_ffn_path():
 # the decode loop as ONE persistent launch (csrc/persist.h) against the launch-per-stage path
 # ------------------------------------------------------------------------------------------------
 def _both_paths(m, img, max_len, **kw):
-    """generate() through the persistent launch (opt-in: TXO_PERSIST=1) and through launches; asserts which path ran."""
+    """generate() through the persistent launch (TXO_PERSIST=1) and through launches (TXO_PERSIST=0); asserts which path ran."""
     import os
-    os.environ["TXO_PERSIST"] = "1"
-    try:
-        out_p = m.generate(img, max_len, **kw)
-        assert m._engine.query(0) == 1, "the persistent launch did not run"
-    finally:
-        os.environ.pop("TXO_PERSIST")
-    out_l = m.generate(img, max_len, **kw)
-    assert m._engine.query(0) == 0
+    outs = []
+    for mode in ("1", "0"):
+        os.environ["TXO_PERSIST"] = mode
+        try:
+            outs.append(m.generate(img, max_len, **kw))
+            assert m._engine.query(0) == int(mode), f"TXO_PERSIST={mode}: the other decode path ran"
+        finally:
+            os.environ.pop("TXO_PERSIST")
     assert m._engine.query(1) == 0, "a persistent launch fell back to launches"
-    return out_p, out_l
+    return outs[0], outs[1]
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])

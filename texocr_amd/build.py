@@ -26,7 +26,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result",
+    # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs.  Every kernel here fits 256 registers, and the attention
+    # kernels read their score tiles with the VALU right after the MFMA: with accumulators in AGPRs the compiler copied ~250
+    # registers per 64-key stage between the two files (v_accvgpr_read / _write: 60 % of the encoder attention's VALU work)
+    extra = os.environ.get("TXO_HIPCC_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form").split()
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result", *extra,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:
         print("[texocr_amd.build]", " ".join(cmd), flush=True)

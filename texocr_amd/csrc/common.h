@@ -86,6 +86,23 @@ __device__ inline float grp4_max(float v) {
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// perf mode (bf16 operands) versions for the encoder-side GEMM epilogues, where the exact forms are a quarter of the FFN-in
+// kernel (erff ~30 VALU instructions per output on top of the MFMAs, no matrix work to hide behind):
+//   erf by Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below one bf16 rounding of the result) on v_rcp_f32 / v_exp_f32.
+// The fp32 parity mode keeps erff / expf / the IEEE division.
+__device__ inline float gelu_fast(float x) {
+    const float z = x * 0.70710678118654752440f, a = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-a * a * 1.4426950408889634f);
+    const float erf_abs = fmaf(-p * t, e, 1.0f);                       // erf(|z|)
+    return 0.5f * x * (1.0f + copysignf(erf_abs, z));
+}
+__device__ inline float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * 1.4426950408889634f)); }
+template <bool FAST> __device__ inline float gelu_sel(float x) { if constexpr (FAST) return gelu_fast(x); else return gelu_erf(x); }
+template <bool FAST> __device__ inline float sigmoid_sel(float x) { if constexpr (FAST) return sigmoid_fast(x); else return sigmoidf(x); }
+
 // 128-byte LDS rows of 8 x 16-byte pieces, piece index XOR-swizzled with the row so that a
 // ds_read_b128 fragment read (16 rows x one piece per lane group) is bank-conflict free.
 __device__ inline int swz128(int row, int piece) { return row * 128 + ((piece ^ (row & 7)) << 4); }

@@ -327,8 +327,8 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
             const float gate = __shfl_xor(mine, 8, 64);       // lane lr + 8 holds this output's gate (all lanes take part)
             if (lr < 8 && em < rows && valid) {
                 const int j = (n0 >> 1) + 8 * h + lr;         // each 16 interleaved weight rows -> 8 outputs
-                if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoidf(gate) + (h ? e_res1 : e_res0);
-                else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(mine * gelu_erf(gate));
+                if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoid_sel<sizeof(T) == 2>(gate) + (h ? e_res1 : e_res0);
+                else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(mine * gelu_sel<sizeof(T) == 2>(gate));
             }
         }
     } else {

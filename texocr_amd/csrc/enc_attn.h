@@ -204,6 +204,7 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, h);
 }
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float EAB_GROW = 6.0f;      // base-2 units: P stays below 64 between shifts (bf16 / f32 keep their relative precision)
 
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
@@ -359,6 +360,217 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const float inv = 1.0f / grp4_sum(l_run[qt]);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                tile[(qt * 16 + lc) * 64 + ((dt * 16 + lg * 4 + r) ^ ((lc & 7) << 2))] = o[qt][dt][r] * inv;
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    const int inner = heads * DH;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = it * 64 + lane, qq = idx >> 4, piece = idx & 15;
+        const int qrow = q0 + wave * 32 + qq;
+        if (qrow < N) {
+            const int c0 = (piece * 4) ^ ((qq & 7) << 2);
+            const float4 v4 = *reinterpret_cast<const float4*>(&tile[qq * 64 + c0]);
+            TO* dst = out + ((size_t)(b * N + qrow)) * inner + head * DH + piece * 4;
+            if constexpr (sizeof(TO) == 4) {
+                *reinterpret_cast<float4*>(dst) = v4;
+            } else {
+                union { bf16 h[4]; uint2 u; } t;
+                t.h[0] = __float2bfloat16(v4.x); t.h[1] = __float2bfloat16(v4.y);
+                t.h[2] = __float2bfloat16(v4.z); t.h[3] = __float2bfloat16(v4.w);
+                *reinterpret_cast<uint2*>(dst) = t.u;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 variant 2 (default in perf mode): the same tiling and the same S^T = K Q^T / O^T += V^T P^T orientation, with the
+// work per score cut to what the matrix pipe cannot do:
+//   * V stays row-major in LDS ([key][64 d], 16-byte pieces XOR-swizzled with (key & 6)); the A operand of O^T += V^T P^T is
+//     read with ds_read_b64_tr_b16, gfx950's transposing LDS read (a 16-lane group fetches 4 keys x 16 d and every lane gets
+//     ITS d for those 4 keys = the k-slots the P accumulator layout dictates).  The 2-byte scatter that transposed V on its
+//     way into LDS (16 ds_write_b16 per thread and stage) is gone;
+//   * the running maximum enters the QK^T MFMA as its initial accumulator (C = -m): scores come out already shifted, and as
+//     long as no query's maximum grows in a stage (a wave-uniform test; true for most stages once the first few have been
+//     seen) nothing is subtracted and the output accumulators are not rescaled;
+//   * the softmax normaliser is accumulated by the matrix pipe too: a fifth A tile of ones makes sum_k P[k] one more
+//     accumulator tile of O^T (4 extra MFMAs per stage instead of 32 adds per lane, and it is the sum of exactly the bf16 P
+//     values that multiply V).
+// Per 64-key stage and wave: 36 MFMAs, 32 v_exp_f32, 16 packed conversions, ~16 three-input maxima.
+// q,k,v: bf16 head-major [B*heads][N][64].  Bound: MFMA bf16 / softmax VALU, about equal.
+template <typename TO>
+__global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
+                                                               const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 128];   // [buf][K | V], 128-byte rows
+    static_assert(sizeof(lds) >= 4 * 32 * 64 * 4, "epilogue tile must fit");
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
+    const int q0 = blockIdx.x * EA_QBLK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lc = lane & 15, lg = lane >> 4;
+    const bf16* Qb = Q + (size_t)bh * N * DH;
+    const bf16* Kb = Kg + (size_t)bh * N * DH;
+    const bf16* Vb = Vg + (size_t)bh * N * DH;
+
+    // Q fragments, pre-scaled by 0.125 * log2(e) (scores in base-2 units: one v_exp_f32 per score)
+    u32x4 qf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qrow = min(q0 + wave * 32 + qt * 16 + lc, N - 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const u32x4 raw = ld16(Qb + (size_t)qrow * DH + ks * 32 + lg * 8);
+            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+            unsigned o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = pack_bf16x2(__uint_as_float(w[k] << 16) * (ATTN_SCALE * LOG2E), __uint_as_float(w[k] & 0xffff0000u) * (ATTN_SCALE * LOG2E));
+            qf[qt][ks] = u32x4{o[0], o[1], o[2], o[3]};
+        }
+    }
+
+    f32x4 o[2][5];                                           // [query tile][d tile 0..3 | normaliser]
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {0.f, 0.f};                             // base of the shifted scores; set by the first stage
+
+    // staging: 64 keys x 128 B = 512 16-byte pieces per operand, 2 per thread
+    u32x4 rk[2], rv[2];
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
+            const int key = min(s * EA_KSTAGE + row, N - 1);
+            rk[i] = ld16(Kb + (size_t)key * DH + piece * 8);
+            rv[i] = ld16(Vb + (size_t)key * DH + piece * 8);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
+            st16(&lds[buf][0][swz128(row, piece)], rk[i]);
+            st16(&lds[buf][1][row * 128 + ((piece ^ (row & 6)) << 4)], rv[i]);
+        }
+    };
+    // transposed V reads: lane (group lg, q = lc >> 2, p = lc & 3) addresses key 4 lg + q (+16 / +32 per instruction), d = 16 dt + 4p..
+    const int vq = lc >> 2, vp = lc & 3, vrow = lg * 4 + vq, vx = vrow & 6;
+    const int vbase = vrow * 128 + ((vp >> 1) << 4) + ((vp & 1) << 3);
+    int vcol[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vcol[dt] = ((2 * dt) ^ vx) << 4;
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+
+    const int nstage = (N + EA_KSTAGE - 1) / EA_KSTAGE;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nstage; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nstage) load_stage(s + 1);
+        const unsigned char* Ks = lds[buf][0];
+        const unsigned char* Vs = lds[buf][1];
+
+        // ---- S^T - m for 64 keys x 32 queries: 16 MFMA, the running maximum as the initial accumulator ----
+        f32x4 sc[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            u32x4 kf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[ks] = ld16(Ks + swz128(kt * 16 + lc, ks * 4 + lg));
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float c = -m_run[qt];
+                f32x4 a = {c, c, c, c};
+                mma16<bf16>(a, kf[0], qf[qt][0]);
+                mma16<bf16>(a, kf[1], qf[qt][1]);
+                sc[qt][kt] = a;
+            }
+        }
+        const int kbase = s * EA_KSTAGE;
+        if (kbase + EA_KSTAGE > N) {
+            asm volatile("; ragged last stage" ::: "memory");    // keep this a branch: if-converted it costs ~60 VALU ops in EVERY stage
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kbase + kt * 16 + lg * 4 + r >= N) { sc[0][kt][r] = -1e30f; sc[1][kt][r] = -1e30f; }
+        }
+        // ---- stage maximum relative to the running one; rescale only when some query's maximum grows ----
+        float rel[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = fmaxf(fmaxf(sc[qt][0][0], sc[qt][0][1]), fmaxf(sc[qt][0][2], sc[qt][0][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt) mx = fmaxf(fmaxf(mx, sc[qt][kt][0]), fmaxf(fmaxf(sc[qt][kt][1], sc[qt][kt][2]), sc[qt][kt][3]));
+            rel[qt] = grp4_max(mx);
+        }
+        const bool first = s == 0;
+        // The shift is only an overflow guard (softmax is invariant to it): it follows the maximum only when some query's
+        // maximum has grown by more than 2^EAB_GROW since the last shift.  Growth by any amount would fire in nearly every
+        // stage (with 32 queries per wave SOME maximum grows in 97 % of the stages of a 589-key row).
+        if (first || __builtin_amdgcn_ballot_w64(rel[0] > EAB_GROW || rel[1] > EAB_GROW) != 0ull) {
+            asm volatile("; a running maximum grows: shift the scores, rescale the accumulators" ::: "memory");   // a real branch (see above)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const float delta = first ? rel[qt] : fmaxf(rel[qt], 0.f);
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                m_run[qt] += delta;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[qt][kt][r] -= delta;
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) o[qt][dt] *= alpha;
+            }
+        }
+        // ---- P = 2^score, packed to the bf16 k-step operands ----
+        u32x4 pb[2][2];                                        // [qt][32-key k-step]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            unsigned pk[8];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                float p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[qt][kt][r]);
+                pk[2 * kt] = pack_bf16x2(p[0], p[1]); pk[2 * kt + 1] = pack_bf16x2(p[2], p[3]);
+            }
+            pb[qt][0] = u32x4{pk[0], pk[1], pk[2], pk[3]};
+            pb[qt][1] = u32x4{pk[4], pk[5], pk[6], pk[7]};
+        }
+        // ---- O^T += V^T P^T (16 MFMA) and the normaliser tile (4 MFMA) ----
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const unsigned char* va = Vs + k2 * (32 * 128) + vbase + vcol[dt];
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uint32_t)(uintptr_t)va);
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(uint32_t)(uintptr_t)(va + 16 * 128));
+                const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                const u32x4 vf = {l2.x, l2.y, h2.x, h2.y};
+                mma16<bf16>(o[0][dt], vf, pb[0][k2]);
+                mma16<bf16>(o[1][dt], vf, pb[1][k2]);
+            }
+            mma16<bf16>(o[0][4], ones, pb[0][k2]);
+            mma16<bf16>(o[1][4], ones, pb[1][k2]);
+        }
+        if (s + 1 < nstage) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise, transpose through LDS (wave-private 32 x 64 f32 tile), store whole rows ----
+    float* tile = reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 64);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float inv = 1.0f / o[qt][4][0];                 // every row of the normaliser tile holds sum_k P[k] of this lane's query
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll

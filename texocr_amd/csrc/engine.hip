@@ -137,6 +137,7 @@ struct Engine : EngineBase {
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
+    bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
     bool look_failed = false;
@@ -163,6 +164,8 @@ struct Engine : EngineBase {
     // ----- profiling -----
     bool prof = false;                // full: per-launch cross-attention events + markers around every encode and step
     bool prof_cross = false;          // light: only the cross-attention dispatches carry events (no extra packets)
+    bool prof_persist = false;        // mode 3: HIP events bound to the persistent decode launch (texocr_amd/csrc/persist.h)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_persist;
     unsigned cross_seq = 0;
     EventPool pool;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_cross, ev_enc, ev_step;
@@ -597,11 +600,11 @@ struct Engine : EngineBase {
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N});
-                hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N,
-                                   cfg.enc_heads);
+                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
+                else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
-                               EpiGluRes{ey, ex, enc_attn[l].bo, D});
+                               EpiGluRes<sizeof(T) == 2>{ey, ex, enc_attn[l].bo, D});
             launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
             gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
             gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, ex, enc_mlp[l].b2, D});
@@ -891,17 +894,18 @@ struct Engine : EngineBase {
     }
 
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
-    bool persist_usable() const {
-        // opt-in (TXO_PERSIST=1): measured on MI355X at batch 64 the persistent launch needs 181 us per position against
-        // 173 us for the 30 launches (profiles/r02_persist_*_stamps.txt: a hand-off costs ~1.5-2 us and the stage bodies are
-        // no shorter than the launched kernels'), so launches stay the default
-        const char* pe = getenv("TXO_PERSIST");
-        if (!pe || atoi(pe) == 0) return false;
+    // Which decode path?  TXO_PERSIST=1 / 0 forces the persistent launch on / off (where it exists: decoder width 256 with 8
+    // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
+    // 256 steps; profiles/r02_persist_ab.txt) -- bf16 with one (image, head) pair per 256-thread group, i.e. 16..64 images, or
+    // two full rounds (113..128 images): 1553 vs 1405 images/s at batch 64, 1999 vs 1924 at 128; other batch sizes leave
+    // groups idle in the attention stages (96 images: 1578 vs 1646), and the fp32 build of the kernel spills.
+    bool persist_usable(int B) const {
         if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
-        if (D == 256 && cfg.dec_heads == 8) return true;
-        if (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2) return true;
-        return false;
+        const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
+        if (!exists) return false;
+        if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
+        return sizeof(T) == 2 && D == 256 && ((B >= 16 && B <= 64) || (B > 112 && B <= 128));
     }
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
@@ -909,7 +913,13 @@ struct Engine : EngineBase {
         auto kern = decode_persist_kernel<T, D_, H_>;
         static bool attr_set = false;
         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-        hipLaunchKernelGGL(kern, dim3(PS_TEAMS * PS_TEAM_BLOCKS), dim3(PS_THREADS), lds, s, pa);
+        if (prof_persist && pool.used + 2 <= pool.ev.size()) {      // events bound to the dispatch itself (its begin / end timestamps)
+            hipEvent_t e0 = pool.next(), e1 = pool.next();
+            hipExtLaunchKernelGGL(kern, dim3(PS_TEAMS * PS_TEAM_BLOCKS), dim3(PS_THREADS), lds, s, e0, e1, 0, pa);
+            ev_persist.push_back({e0, e1});
+        } else {
+            hipLaunchKernelGGL(kern, dim3(PS_TEAMS * PS_TEAM_BLOCKS), dim3(PS_THREADS), lds, s, pa);
+        }
         return 0;
     }
     // returns 0 (done), TXO_E_STATE (the launch gave up: redo with launches), or an error
@@ -1003,7 +1013,7 @@ struct Engine : EngineBase {
         }
         if (int r = decode_begin(enc, B, N, eos, s)) return r;   // eos also decides whether the BOS column counts
         last_persist = false;
-        if (persist_usable()) {
+        if (persist_usable(B)) {
             int steps = 0;
             const int pr = generate_persist(B, N, max_len, eos, tokens_out, logits_out, &steps, s);
             if (pr == 0) { last_persist = true; if (n_steps) *n_steps = steps; return 0; }
@@ -1164,8 +1174,9 @@ struct Engine : EngineBase {
         return 0;
     }
     int profile_enable(int on) override {
-        prof = on == 1; prof_cross = on == 2;
-        ev_cross.clear(); ev_enc.clear(); ev_step.clear(); pool.used = 0;
+        prof = on == 1; prof_cross = on == 2; prof_persist = on == 3;
+        ev_cross.clear(); ev_enc.clear(); ev_step.clear(); ev_persist.clear(); pool.used = 0;
+        if (prof_persist) while (pool.ev.size() < 64) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); pool.ev.push_back(e); }
         if (prof_cross) {           // events for 16 generate() calls, created now
             const size_t want = (size_t)16 * 2 * cfg.dec_layers * Tmax / 4;
             while (pool.ev.size() < want) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); pool.ev.push_back(e); }
@@ -1173,7 +1184,7 @@ struct Engine : EngineBase {
         return 0;
     }
     int profile_read(int kind, double* avg_ms, int64_t* count) override {
-        auto& v = kind == 0 ? ev_cross : (kind == 1 ? ev_enc : ev_step);
+        auto& v = kind == 0 ? ev_cross : (kind == 1 ? ev_enc : (kind == 2 ? ev_step : ev_persist));
         double tot = 0; int64_t n = 0;
         for (auto& p : v) {
             float ms = 0;

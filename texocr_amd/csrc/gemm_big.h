@@ -104,6 +104,7 @@ template <typename T> struct EpiHeads {           // scatter n = (which, head, d
         if (valid) (*this)(m, n, v);
     }
 };
+template <bool FAST = false>                      // FAST: perf mode (bf16 operands), see common.h
 struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoid(g+bg) + resid[m][j..]   (fp32 stream)
     float* y; const float* resid; const float* bias; int D;   // bias is in the interleaved order
     static constexpr bool PAIRED = true;
@@ -111,7 +112,7 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
         float bv[8], bg[8], r[8];
         load8(bias + nv, bv); load8(bias + ng, bg); load8(resid + (size_t)m * D + j, r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoidf(g[e] + bg[e]) + r[e];
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoid_sel<FAST>(g[e] + bg[e]) + r[e];
         store8<float>(y + (size_t)m * D + j, v);
     }
     static constexpr bool HAS_ROW = true;
@@ -121,7 +122,7 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
     __device__ inline void rowop(int m, int j, float (&r)[8]) const { load8(resid + (size_t)m * D + j, r); }
     __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * sigmoidf(g[e] + cb[8 + e]) + r[e];
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * sigmoid_sel<FAST>(g[e] + cb[8 + e]) + r[e];
         if (valid) store8<float>(y + (size_t)m * D + j, v);
     }
 };
@@ -132,7 +133,7 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
         float bv[8], bg[8];
         load8(bias + nv, bv); load8(bias + ng, bg);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_erf(g[e] + bg[e]);
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_sel<sizeof(T) == 2>(g[e] + bg[e]);
         store8<T>(h + (size_t)m * F + j, v);
     }
     static constexpr bool HAS_ROW = false;
@@ -142,7 +143,7 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
     __device__ inline void rowop(int, int, float (&)[8]) const {}
     __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * gelu_erf(g[e] + cb[8 + e]);
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * gelu_sel<sizeof(T) == 2>(g[e] + cb[8 + e]);
         if (valid) store8<T>(h + (size_t)m * F + j, v);
     }
 };

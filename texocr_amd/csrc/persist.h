@@ -17,8 +17,8 @@
 // groups.
 //
 // Hand-off (one per stage, all-to-all inside the team): every storing wave drains its stores (s_waitcnt vmcnt(0)),
-// workgroup barrier, ONE agent-scope atomic add on the team's arrival counter; a consumer polls that counter with sc1
-// loads from one lane, workgroup barrier, then reads the rows with sc1 loads (never from its CU's L1, which other CUs'
+// workgroup barrier, ONE plain store of the stage number into the workgroup's word of the team's flag line; a consumer
+// polls that line with sc1 loads from one wave, workgroup barrier, then reads the rows with sc1 loads (never from its CU's L1, which other CUs'
 // stores do not refresh; the XCD's L2 -- the coherence point of its 32 CUs -- serves them).  Stores are plain (they stay
 // in that L2).  This is valid only while producer and consumer share an XCD: each workgroup ORs its XCC id into a
 // per-team mask, and after the first hand-off every workgroup checks that its team's mask has ONE bit; otherwise the
@@ -39,7 +39,7 @@ constexpr int PS_TEAMS = 8, PS_TEAM_BLOCKS = 32, PS_THREADS = 512, PS_MAXLD = 8;
 constexpr int PS_MAX_STAGES = 7 * PS_MAXLD + 2, PS_STAMP_RANKS = 4, PS_STAMP_WORDS = 5;
 
 struct PersistCtl {                       // zeroed before every launch
-    unsigned counter[PS_TEAMS][32];       // arrival counters, a 128-byte line each
+    unsigned flags[PS_TEAMS][32];         // arrival flags: one 128-byte line per team, one word per workgroup (TeamSync)
     unsigned xcc_mask[PS_TEAMS];          // OR of (1 << XCC id) over the team's workgroups
     unsigned eos_rows[PS_TEAMS];          // rows of the team that contain eos so far
     int last_first_eos[PS_TEAMS];         // position at which a row of the team FIRST produced eos, maximum over rows
@@ -71,26 +71,37 @@ template <typename T> struct PersistArgs {
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
 };
 
-// the team's arrival counter, seen from one workgroup
+// The team's arrival flags, seen from one workgroup.  Every workgroup owns ONE word of its team's 128-byte flag line and stores
+// the number of the stage it has finished there (a plain store: it lands in the XCD's L2 like the stage's rows, and it is issued
+// only after every wave's row stores have been acknowledged).  A consumer's first wave reads the whole line with one sc1 load per
+// poll (lane r reads workgroup r's word) until every word has reached the stage it waits for.  No atomic is involved: an
+// agent-scope atomic add executes at the memory side, ~0.5-1 us away, and cost more than the stage's arithmetic
+// (profiles/r02_persist_v4_stamps.txt: "pub").
 struct TeamSync {
-    unsigned* cnt; unsigned target; unsigned* fail; int* lds_dead; bool armed, dead;
+    unsigned* flags;                                          // this team's line: PS_TEAM_BLOCKS words
+    int rank; unsigned epoch;                                 // stages this workgroup has finished
+    unsigned* fail; int* lds_dead; bool armed, dead;
     unsigned long long* stp;                                  // diagnostic: 5 ticks per stage (wait begin / end, drain begin / end, published)
     __device__ inline void operator()() {                     // wait until every workgroup of the team has finished the previous stage
         if (!armed) return;
         armed = false;
-        if (threadIdx.x == 0) {
-            if (stp) stp[0] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x < 64) {
+            if (stp && threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
+            const int lane = threadIdx.x;
             unsigned spins = 0;
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            for (;;) {
+                const unsigned v = lane < PS_TEAM_BLOCKS ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+                if (__builtin_amdgcn_ballot_w64(v < epoch) == 0ull) break;
                 __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 1023u) == 0u) {                // ~ every 0.3 ms: give up after ~80 ms or when another workgroup has
                     if (spins > (1u << 18) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        atomicOr(fail, 1u); *lds_dead = 1; break;
+                        if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
+                        break;
                     }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (stp) stp[1] = __builtin_amdgcn_s_memrealtime();
+            if (stp && threadIdx.x == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
         }
         __syncthreads();
         dead = dead || *lds_dead != 0;
@@ -99,12 +110,12 @@ struct TeamSync {
         if (stp && threadIdx.x == 0) stp[2] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains
         __syncthreads();
+        ++epoch;
         if (threadIdx.x == 0) {
             if (stp) stp[3] = __builtin_amdgcn_s_memrealtime();
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(flags + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain global_store_dword
             if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[4] = __builtin_amdgcn_s_memrealtime(); stp += 5; }
         }
-        target += PS_TEAM_BLOCKS;
         armed = true;
     }
 };
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         while (__builtin_amdgcn_s_memrealtime() - t0 < until) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
-    TeamSync ts{&ctl->counter[team][0], 0u, &ctl->fail, lds_dead, false, false, nullptr};
+    TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, nullptr};
     bool placement_checked = false;
 
     DecGemmArgs<T> gb{};
