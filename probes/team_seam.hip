@@ -12,6 +12,10 @@
 //       served by the L2 the producer wrote) -- only meaningful when a team's blocks share an XCD; the probe reports the
 //       XCC ids it saw and counts wrong words
 //   F2  release/acquire: plain stores, agent release fence, atomic; consumer polls, agent acquire fence, plain loads
+//   F3  XCD-local rows as F1, but NO atomic: every block stores the stage number into its word of the team's 128-byte flag line
+//       (plain store); the consumer's first wave reads the line with one sc1 load per poll (lane r = block r)
+//   F4  as F3, polled with SCALAR loads (s_load_dwordx16 ... glc: lgkmcnt, not vmcnt -- a polling wave could keep vector loads
+//       in flight)
 //   L   one launch per stage (grid = all teams), the structure the engine has today
 // Optional load: every LOADEVERY-th stage each block also streams STREAM_KB of a large buffer with non-temporal loads
 // (the cross-attention stage of the real step).
@@ -30,6 +34,7 @@ constexpr int R = 16, D = 256;
 struct Args {
     uint32_t* act;            // [teams][2][R][D]
     unsigned* counter;        // [teams] on lines of their own (32 words apart)
+    unsigned* flagline;       // [teams][64] words: forms 3 / 4
     unsigned* fail;           // spin time-outs
     unsigned* xcc;            // [blocks] XCC id seen
     const u32x4* big; size_t big_vec;   // streaming buffer
@@ -89,7 +94,34 @@ __global__ __launch_bounds__(512) void team_chain(Args a) {
     bool dead = false;
     for (int s = 0; s < a.stages; ++s) {
         if (s > 0) {   // wait for every block of the team to have finished stage s-1
-            if (tid == 0) {
+            if constexpr (FORM == 3) {
+                if (tid < 64) {
+                    const unsigned* fl = a.flagline + team * 64;
+                    unsigned spins = 0;
+                    for (;;) {
+                        const unsigned v = tid < a.S ? poll_sc1(fl + tid) : (unsigned)s;
+                        if (__builtin_amdgcn_ballot_w64(v < (unsigned)s) == 0ull) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { if (tid == 0) atomicAdd(a.fail, 1u); break; }
+                    }
+                }
+            } else if constexpr (FORM == 4) {
+                if (tid < 64) {
+                    const unsigned* fl = a.flagline + team * 64;      // 64 words = two 128-byte lines (S <= 64)
+                    unsigned spins = 0;
+                    for (;;) {
+                        typedef unsigned u16v __attribute__((ext_vector_type(16)));
+                        u16v w0, w1;
+                        asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                                     : "=&s"(w0), "=&s"(w1) : "s"(fl) : "memory");
+                        unsigned mn = 0xffffffffu;
+                        for (int i = 0; i < 16; ++i) { mn = min(mn, w0[i]); if (a.S > 16) mn = min(mn, w1[i]); }
+                        if (mn >= (unsigned)s) break;
+                        __builtin_amdgcn_s_sleep(1);
+                        if (++spins > (1u << 22)) { if (tid == 0) atomicAdd(a.fail, 1u); break; }
+                    }
+                }
+            } else if (tid == 0) {
                 const unsigned want = (unsigned)s * (unsigned)a.S;
                 unsigned spins = 0;
                 while (poll_sc1(cnt) < want) {
@@ -101,12 +133,13 @@ __global__ __launch_bounds__(512) void team_chain(Args a) {
             }
             __syncthreads();
         }
-        stage_body<FORM>(a, team, rank, s, lds, sink);
+        stage_body<(FORM >= 3 ? 1 : FORM)>(a, team, rank, s, lds, sink);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // every storing wave drains
         __syncthreads();
         if (tid == 0) {
             if constexpr (FORM == 2) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if constexpr (FORM >= 3) __hip_atomic_store(a.flagline + team * 64 + rank, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (tid == 0 && rank == 0) a.ticks[team] = __builtin_amdgcn_s_memrealtime() - t0;
@@ -136,7 +169,7 @@ int main(int argc, char** argv) {
     u32x4* big; hipMalloc(&big, big_bytes); hipMemset(big, 1, big_bytes);
     hipStream_t st; hipStreamCreate(&st);
     printf("form teams S thr stream_kb | us/stage (host) | in-kernel us/stage min..max | wrong words | spin fails | xcc spread per team\n");
-    for (int thr : {256, 512}) for (int S : {32, 64}) for (int stream_kb : {0, 300}) for (int form : {0, 1, 2, 3}) {
+    for (int thr : {256, 512}) for (int S : {32, 64}) for (int stream_kb : {0, 300}) for (int form : {0, 1, 2, 3, 4, 5}) {
         const int teams = 8, blocks = teams * S;
         if (blocks * thr > 256 * 512 * 2) continue;
         if (thr == 512 && S == 64) continue;                                    // 512 blocks of 512 threads: not co-resident with headroom
@@ -144,19 +177,21 @@ int main(int argc, char** argv) {
         a.teams = teams; a.S = S; a.stages = stages; a.stream_kb = stream_kb; a.load_every = 7;
         a.big = big; a.big_vec = big_bytes / 16;
         hipMalloc(&a.act, (size_t)teams * 2 * R * D * 4);
-        hipMalloc(&a.counter, teams * 32 * 4); hipMalloc(&a.fail, 64); hipMalloc(&a.xcc, blocks * 4); hipMalloc(&a.ticks, teams * 8);
+        hipMalloc(&a.counter, teams * 32 * 4); hipMalloc(&a.flagline, teams * 64 * 4); hipMalloc(&a.fail, 64); hipMalloc(&a.xcc, blocks * 4); hipMalloc(&a.ticks, teams * 8);
         std::vector<uint32_t> init((size_t)teams * 2 * R * D);
         for (size_t i = 0; i < init.size(); ++i) init[i] = (uint32_t)(i * 2654435761u + 12345u);
         double best = 1e30; long wrong = 0; unsigned fails = 0; double kmin = 1e30, kmax = 0;
         std::vector<unsigned> xcc(blocks);
         for (int rep = 0; rep < 6; ++rep) {
             hipMemcpy(a.act, init.data(), init.size() * 4, hipMemcpyHostToDevice);
-            hipMemset(a.counter, 0, teams * 32 * 4); hipMemset(a.fail, 0, 64); hipMemset(a.ticks, 0, teams * 8);
+            hipMemset(a.counter, 0, teams * 32 * 4); hipMemset(a.flagline, 0, teams * 64 * 4); hipMemset(a.fail, 0, 64); hipMemset(a.ticks, 0, teams * 8);
             hipDeviceSynchronize();
             auto t0 = std::chrono::high_resolution_clock::now();
             if (form == 0) hipLaunchKernelGGL(team_chain<0>, dim3(blocks), dim3(thr), 0, st, a);
             else if (form == 1) hipLaunchKernelGGL(team_chain<1>, dim3(blocks), dim3(thr), 0, st, a);
             else if (form == 2) hipLaunchKernelGGL(team_chain<2>, dim3(blocks), dim3(thr), 0, st, a);
+            else if (form == 4) hipLaunchKernelGGL(team_chain<3>, dim3(blocks), dim3(thr), 0, st, a);
+            else if (form == 5) hipLaunchKernelGGL(team_chain<4>, dim3(blocks), dim3(thr), 0, st, a);
             else for (int s = 0; s < stages; ++s) hipLaunchKernelGGL(stage_launch, dim3(blocks), dim3(thr), 0, st, a, s);
             hipError_t e = hipStreamSynchronize(st);
             const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -172,21 +207,21 @@ int main(int argc, char** argv) {
                 for (int i = 0; i < R * D; ++i) wrong += g[i] != x[i];
             }
             unsigned f[2]; hipMemcpy(f, a.fail, 8, hipMemcpyDeviceToHost); fails += f[0];
-            if (form < 3) {
+            if (form != 3) {
                 std::vector<unsigned long long> tk(teams); hipMemcpy(tk.data(), a.ticks, teams * 8, hipMemcpyDeviceToHost);
                 for (auto v : tk) { kmin = std::min(kmin, v / 100.0 / stages); kmax = std::max(kmax, v / 100.0 / stages); }
                 hipMemcpy(xcc.data(), a.xcc, blocks * 4, hipMemcpyDeviceToHost);
             }
         }
         char spread[128] = "-";
-        if (form < 3) {   // number of distinct XCC ids inside each team
+        if (form != 3) {   // number of distinct XCC ids inside each team
             int off = 0;
             for (int t = 0; t < teams; ++t) { unsigned m = 0; for (int b = t; b < blocks; b += teams) m |= 1u << xcc[b]; off += snprintf(spread + off, sizeof spread - off, "%d ", __builtin_popcount(m)); }
         }
-        printf("%s %d %2d %3d %3d | %7.2f | %6.2f .. %6.2f | %ld | %u | %s\n", form == 3 ? "L " : (form == 0 ? "F0" : form == 1 ? "F1" : "F2"),
-               teams, S, thr, stream_kb, best, form < 3 ? kmin : 0.0, form < 3 ? kmax : 0.0, wrong, fails, spread);
+        printf("%s %d %2d %3d %3d | %7.2f | %6.2f .. %6.2f | %ld | %u | %s\n", form == 3 ? "L " : (form == 0 ? "F0" : form == 1 ? "F1" : form == 2 ? "F2" : form == 4 ? "F3" : "F4"),
+               teams, S, thr, stream_kb, best, form != 3 ? kmin : 0.0, form != 3 ? kmax : 0.0, wrong, fails, spread);
         fflush(stdout);
-        hipFree(a.act); hipFree(a.counter); hipFree(a.fail); hipFree(a.xcc); hipFree(a.ticks);
+        hipFree(a.act); hipFree(a.counter); hipFree(a.flagline); hipFree(a.fail); hipFree(a.xcc); hipFree(a.ticks);
     }
     return 0;
 }

@@ -29,7 +29,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs.  Every kernel here fits 256 registers, and the attention
     # kernels read their score tiles with the VALU right after the MFMA: with accumulators in AGPRs the compiler copied ~250
     # registers per 64-key stage between the two files (v_accvgpr_read / _write: 60 % of the encoder attention's VALU work)
-    extra = os.environ.get("TXO_HIPCC_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form").split()
+    # -ffp-contract=on: a*b+c fuses only INSIDE one source expression (hipcc's default, "fast", lets the backend fuse across
+    # statements, and it decides per surrounding code: the same inlined tile function then rounds differently in the
+    # per-stage kernels and in the persistent decode kernel, which are required to give the same bits).
+    extra = os.environ.get("TXO_HIPCC_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form -ffp-contract=on").split()
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result", *extra,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
     if verbose:

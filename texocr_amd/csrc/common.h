@@ -53,33 +53,114 @@ __device__ inline void mma16<bf16>(f32x4& acc, const u32x4& a, const u32x4& b) {
                                                   acc, 0, 0, 0);
 }
 
-// ---- wave reductions ------------------------------------------------------------------
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// ---- cross-lane exchange without the LDS crossbar -----------------------------------------------------------------
+// hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe operation, ~100 cycles of latency); the reductions of this
+// path are chains of 4-6 DEPENDENT exchanges inside latency-bound kernels (LayerNorm prologues, the decode attention's
+// score butterflies and accumulator sums, arg-max), so they are built from VALU-only exchanges instead:
+//   partner at lane ^ 1, ^ 2        DPP quad_perm
+//   partner 7 - i inside 8 lanes    DPP row_half_mirror        (after the two quad steps every lane of a quad holds the
+//   partner 15 - i inside 16 lanes  DPP row_mirror              same value, so WHICH lane of the partner quad is read does
+//   partner row (16 lanes) / half   v_permlane16_swap / v_permlane32_swap     not matter: same sums as a xor butterfly)
+//   partner at lane ^ 8             DPP row_ror:8 (a rotation by 8 inside a row of 16 IS xor 8)
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+#ifdef TXO_SHFL_REDUCE   // diagnostic build: the same exchanges through ds_bpermute
+template <int CTRL> __device__ inline int dpp_mov(int v) {
+    const int l = threadIdx.x & 63;
+    const int src = CTRL == DPP_XOR1 ? l ^ 1 : CTRL == DPP_XOR2 ? l ^ 2 : CTRL == DPP_HALF_MIRROR ? (l & ~7) | (7 - (l & 7))
+                  : CTRL == DPP_MIRROR ? (l & ~15) | (15 - (l & 15)) : l ^ 8;
+    return __shfl(v, src, 64);
+}
+template <int CTRL> __device__ inline float dpp_mov(float v) { return __builtin_bit_cast(float, dpp_mov<CTRL>(__builtin_bit_cast(int, v))); }
+#else
+template <int CTRL> __device__ inline float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL> __device__ inline int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+#endif
+// the other 16-lane row of a row pair (lane ^ 16) / the other 32-lane half (lane ^ 32): a = the even rows' (lower half's) value,
+// b = the odd rows' (upper half's), in every lane of the pair.  The two results are copied into scalars BEFORE the bit cast:
+// this clang's __builtin_bit_cast(float, r[1]) on an element of the returned vector reads element 0 (the index is dropped),
+// which silently turns every reduction below into v + v (probes/reduce_check.hip, probes/swap_raw.hip).
+__device__ inline void swap16(float v, float& a, float& b) {
+#ifdef TXO_SHFL_REDUCE
+    { const float o = __shfl_xor(v, 16, 64); const bool odd = (threadIdx.x >> 4) & 1; a = odd ? o : v; b = odd ? v : o; return; }
+#endif
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0); b = __builtin_bit_cast(float, r1);
+}
+__device__ inline void swap32(float v, float& a, float& b) {
+#ifdef TXO_SHFL_REDUCE
+    { const float o = __shfl_xor(v, 32, 64); const bool hi = (threadIdx.x >> 5) & 1; a = hi ? o : v; b = hi ? v : o; return; }
+#endif
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    a = __builtin_bit_cast(float, r0); b = __builtin_bit_cast(float, r1);
+}
+// value of the lane at (lane ^ 16) / (lane ^ 32): after the swap one of the two results holds the partner row / half for the
+// even rows (lower half) and the other for the odd rows (upper half)
+__device__ inline float xor16(float v) { float a, b; swap16(v, a, b); return ((threadIdx.x >> 4) & 1) ? a : b; }
+__device__ inline float xor32(float v) { float a, b; swap32(v, a, b); return ((threadIdx.x >> 5) & 1) ? a : b; }
+__device__ inline int xor16(int v) { return __builtin_bit_cast(int, xor16(__builtin_bit_cast(float, v))); }
+__device__ inline int xor32(int v) { return __builtin_bit_cast(int, xor32(__builtin_bit_cast(float, v))); }
+
+// ---- wave reductions (every lane of the reduced group ends up with the result) ------------------------------------
+// The library is built with -ffp-contract=on (build.py): a multiply and an add fuse only inside one source expression,
+// so these adds are never fused with the multiply that produced their operand, and the same tile function gives the same
+// bits in every kernel it is inlined into (the per-stage kernels and the persistent decode kernel).
+// reduce over the 4 lanes of a quad / the 2 lanes (lane, lane ^ 8)
+__device__ inline float quad_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v);
     return v;
 }
-__device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ inline float xor8_sum(float v) {
+    return v + dpp_mov<DPP_ROR8>(v);
+}
+// reduce over the 8 lanes that share (lane >> 3)
+__device__ inline float row8_sum(float v) {
+    v = quad_sum(v); v += dpp_mov<DPP_HALF_MIRROR>(v);
     return v;
 }
 // reduce over the 16 lanes that share (lane >> 4)
 __device__ inline float row16_sum(float v) {
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row8_sum(v); v += dpp_mov<DPP_MIRROR>(v);
+    return v;
+}
+__device__ inline float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v)); v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v)); v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
     return v;
 }
 // reduce over the 4 lane groups (lanes l, l^16, l^32, l^48)
 __device__ inline float grp4_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    float a, b;
+    swap16(v, a, b); v = a + b;
+    swap32(v, a, b); return a + b;
 }
 __device__ inline float grp4_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    float a, b;
+    swap16(v, a, b); v = fmaxf(a, b);
+    swap32(v, a, b); return fmaxf(a, b);
+}
+__device__ inline float wave_sum(float v) { return grp4_sum(row16_sum(v)); }
+__device__ inline float wave_max(float v) { return grp4_max(row16_max(v)); }
+__device__ inline int wave_sum(int v) {
+    v += dpp_mov<DPP_XOR1>(v); v += dpp_mov<DPP_XOR2>(v); v += dpp_mov<DPP_HALF_MIRROR>(v); v += dpp_mov<DPP_MIRROR>(v);
+    v += xor16(v); v += xor32(v);
     return v;
+}
+// arg-max over the wave: largest value, lowest index among equals (torch.argmax); the combine is commutative and
+// associative, so the mirrored partners above serve
+__device__ inline void wave_argmax(float& best, int& bi) {
+    auto take = [&](float ov, int oi) { if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; } };
+    take(dpp_mov<DPP_XOR1>(best), dpp_mov<DPP_XOR1>(bi));
+    take(dpp_mov<DPP_XOR2>(best), dpp_mov<DPP_XOR2>(bi));
+    take(dpp_mov<DPP_HALF_MIRROR>(best), dpp_mov<DPP_HALF_MIRROR>(bi));
+    take(dpp_mov<DPP_MIRROR>(best), dpp_mov<DPP_MIRROR>(bi));
+    take(xor16(best), xor16(bi));
+    take(xor32(best), xor32(bi));
 }
 
 // exact-erf GELU (F.gelu default, reference attention.py:17) and sigmoid (nn.GLU, :98)

@@ -234,7 +234,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
                     const float4 q = *reinterpret_cast<const float4*>(a.pos_emb + (size_t)t * D + c);
                     v[i] = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
                 } else {
-                    v[i] = ldc_f4<COH>(a.y + (size_t)img * D + c);
+                    v[i] = ldc_f4_at<COH>(a.y, (size_t)img * D + c);
                 }
             }
             if constexpr (APRO == APRO_LN2) ln64<NVMAX>(v, nv, g, b, inv_d);
@@ -312,9 +312,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         }
 #pragma unroll
         for (int p = 0; p < WB; ++p) if (p0 + p < NP) {
-            float v = accp[p];
-            v += __shfl_xor(v, 1, 64);
-            v += __shfl_xor(v, 2, 64);
+            const float v = quad_sum(accp[p]);
             if (prt == 0) qkv[p0 + p][pd] = v;
         }
     }
@@ -366,8 +364,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
             for (int e = 0; e < PER16; ++e) d = fmaf(qv[e], kf[e], d);
             // the K registers of this slot are dead now: request the matching V rows into their place
             if constexpr (!V_EARLY) rv[u] = ld_kv(Vb + row_off(min(key, Lm1)) + sub * PER16);
-#pragma unroll
-            for (int o = LPR / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);   // butterfly: all LPR lanes get the dot
+            d = LPR == 8 ? row8_sum(d) : row16_sum(d);                         // all LPR lanes of the key get the dot
             d = key < L ? d : -3.0e38f;
             sc[u] = d;
             mx = fmaxf(mx, d);
@@ -411,8 +408,8 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     // ---- 5. reduce over key groups (shuffles), waves (LDS), normalise, merge heads ----
 #pragma unroll
     for (int e = 0; e < PER16; ++e) {
-#pragma unroll
-        for (int o = 32; o >= LPR; o >>= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+        if constexpr (LPR == 8) acc[e] = xor8_sum(acc[e]);                      // the other key of the row (lane ^ 8)
+        acc[e] = grp4_sum(acc[e]);
     }
     l_run = wave_sum(l_run);
     if (kq == 0) {

@@ -52,6 +52,19 @@ template <bool COH> __device__ inline u32x4 ldc16(const void* p) {
         return r;
     }
 }
+// 16 bytes at element offset `off` of a WAVE-UNIFORM base: COH = one buffer_load_dwordx4 ... sc1 (the 8-byte atomic loads of
+// ldc16 move 16 bytes as two requests; 8-byte accesses run at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md)
+template <bool COH, typename E> __device__ inline u32x4 ldc16_at(const E* base, size_t off) {
+    if constexpr (!COH) return ld16(base + off);
+    else {
+        const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(base), 0, 0x7fffffff, 0x00020000);
+        return __builtin_amdgcn_raw_buffer_load_b128(r, (int)(off * sizeof(E)), 0, 16);          // aux 16 = sc1
+    }
+}
+template <bool COH> __device__ inline float4 ldc_f4_at(const float* base, size_t off) {
+    const u32x4 r = ldc16_at<COH>(base, off);
+    return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
 template <bool COH> __device__ inline float4 ldc_f4(const float* p) {
     const u32x4 r = ldc16<COH>(p);
     return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
@@ -209,7 +222,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
         const int m = min(m0 + lr, rows - 1);
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
-            fa[c] = ldc16<COH>(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+            fa[c] = ldc16_at<COH>(a.A, (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
     };
     if constexpr (HASPRE) {
         static_assert(FIXED && wfrag_regs(KW, BN) <= WBUF_REGS, "prefetched fragments need a compile-time K that fits the buffer");
@@ -262,7 +275,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
         } else {
 #pragma unroll
             for (int i = 0; i < NVMAX; ++i) if (i < nv)
-                v[i] = ldc_f4<COH>(a.y + (size_t)m * K + i * 64 + sub * 4);
+                v[i] = ldc_f4_at<COH>(a.y, (size_t)m * K + i * 64 + sub * 4);
         }
         pf();
         if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, g, b, inv_d);
@@ -324,7 +337,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
 #pragma unroll
         for (int h = 0; h < (TWO ? 2 : 1); ++h) {
             const float mine = (h ? c1 : c0) + (h ? e_b1 : e_b0);
-            const float gate = __shfl_xor(mine, 8, 64);       // lane lr + 8 holds this output's gate (all lanes take part)
+            const float gate = dpp_mov<DPP_ROR8>(mine);       // lane lr ^ 8 holds this output's gate (rotation by 8 inside the row of 16)
             if (lr < 8 && em < rows && valid) {
                 const int j = (n0 >> 1) + 8 * h + lr;         // each 16 interleaved weight rows -> 8 outputs
                 if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoid_sel<sizeof(T) == 2>(gate) + (h ? e_res1 : e_res0);

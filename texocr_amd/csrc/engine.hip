@@ -909,7 +909,7 @@ struct Engine : EngineBase {
     }
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
-        const size_t lds = 2 * persist_group_lds<T, D_, H_>() + 16;
+        const size_t lds = persist_lds_bytes<T, D_, H_>();
         auto kern = decode_persist_kernel<T, D_, H_>;
         static bool attr_set = false;
         if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
@@ -988,14 +988,17 @@ struct Engine : EngineBase {
                 const unsigned long long* d = &h[((size_t)k * PS_STAMP_RANKS + r) * PS_MAX_STAGES * PS_STAMP_WORDS];
                 if (!d[2]) continue;
                 const unsigned long long t0 = d[2];
-                fprintf(f, "team %d rank %d: position span %.2f us\n", k, ranks[r], (d[(ns - 1) * 5 + 4] - t0) / 100.0);
+                fprintf(f, "team %d rank %d: position span %.2f us\n", k, ranks[r], (d[(ns - 1) * PS_STAMP_WORDS + 4] - t0) / 100.0);
                 if (k > 1) continue;                           // the per-stage table for two teams is enough
                 for (int i = 0; i < ns; ++i) {
-                    const unsigned long long* e = d + i * 5;
+                    const unsigned long long* e = d + i * PS_STAMP_WORDS;
                     const char* nm = i < 7 * cfg.dec_layers ? names[i % 7] : (i == 7 * cfg.dec_layers ? "LNf+logits" : "argmax+append");
-                    fprintf(f, "  L%-2d %-30s poll %5.2f  work %5.2f  drain %5.2f  pub %5.2f | end %7.2f\n", i < 7 * cfg.dec_layers ? i / 7 : -1, nm,
+                    fprintf(f, "  L%-2d %-30s poll %5.2f  work %5.2f  drain %5.2f  pub %5.2f | end %7.2f", i < 7 * cfg.dec_layers ? i / 7 : -1, nm,
                             e[0] ? (e[1] - e[0]) / 100.0 : 0.0, e[1] ? (e[2] - e[1]) / 100.0 : 0.0, (e[3] - e[2]) / 100.0, (e[4] - e[3]) / 100.0,
                             (e[4] - t0) / 100.0);
+                    if (e[5] && e[1])      // GEMM tile of the workgroup's first group: rows read + MFMAs | K reduction | epilogue
+                        fprintf(f, " | tile: seen->mfma done %5.2f  reduce %5.2f  epilogue+stores %5.2f", (e[6] - e[1]) / 100.0, (e[7] - e[6]) / 100.0, (e[2] - e[7]) / 100.0);
+                    fprintf(f, "\n");
                 }
             }
         fclose(f);

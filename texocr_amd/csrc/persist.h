@@ -36,7 +36,7 @@
 namespace txo {
 
 constexpr int PS_TEAMS = 8, PS_TEAM_BLOCKS = 32, PS_THREADS = 512, PS_MAXLD = 8;
-constexpr int PS_MAX_STAGES = 7 * PS_MAXLD + 2, PS_STAMP_RANKS = 4, PS_STAMP_WORDS = 5;
+constexpr int PS_MAX_STAGES = 7 * PS_MAXLD + 2, PS_STAMP_RANKS = 4, PS_STAMP_WORDS = 8;   // 5 hand-off ticks + the tile's {entry, operands consumed, reduced}
 
 struct PersistCtl {                       // zeroed before every launch
     unsigned flags[PS_TEAMS][32];         // arrival flags: one 128-byte line per team, one word per workgroup (TeamSync)
@@ -114,7 +114,7 @@ struct TeamSync {
         if (threadIdx.x == 0) {
             if (stp) stp[3] = __builtin_amdgcn_s_memrealtime();
             __hip_atomic_store(flags + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // a plain global_store_dword
-            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[4] = __builtin_amdgcn_s_memrealtime(); stp += 5; }
+            if (stp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stp[4] = __builtin_amdgcn_s_memrealtime(); stp += PS_STAMP_WORDS; }
         }
         armed = true;
     }
@@ -132,6 +132,16 @@ constexpr size_t persist_group_lds() {
     if (g < 8192) g = 8192;                                   // cross-wave K reduction
     if (g < sizeof(DecAttnLds<false>)) g = sizeof(DecAttnLds<false>);
     return (g + 255) & ~(size_t)255;
+}
+
+// FFN-out weights resident in LDS (see the kernel): one tile's fragments per 256-thread group, 16 bytes x KW per thread
+template <typename T, int D_>
+constexpr bool persist_w2_in_lds() {
+    return sizeof(T) == 2 && ps_kw_half<T>(4 * D_) > 0 && wfrag_regs(ps_kw_half<T>(4 * D_), 16) <= WBUF_REGS && D_ / 16 == 16;
+}
+template <typename T, int D_, int HEADS_>
+constexpr size_t persist_lds_bytes() {
+    return 2 * persist_group_lds<T, D_, HEADS_>() + 16 + (persist_w2_in_lds<T, D_>() ? 2 * (size_t)WBUF_REGS * 256 * 16 : 0);
 }
 
 template <typename T, int D_, int HEADS_>
@@ -198,6 +208,24 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     WBuf wbuf;
     if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
 
+    // FFN-out (K = 4D: the longest weight rows of the step, 32 KB per tile) waited ~1.7 us per stage for its fragments to come
+    // from the Infinity Cache (profiles/r02_persist_v6_stamps.txt: "reduce").  Its 16 tiles per layer are therefore pinned to
+    // 8 workgroups PER LAYER (ranks 8l .. 8l+7), which keep their tile's fragments in LDS for the whole decode: every thread
+    // parks its own 8 x 16 bytes there once and reads them back each position (thread-private: no synchronisation, same
+    // fragments -> same bits as the launch path).
+    constexpr bool W2_LDS_OK = persist_w2_in_lds<T, D_>();
+    const bool w2_lds = W2_LDS_OK && a.Ld <= PS_TEAM_BLOCKS / 8;
+    const int w2_layer = rank >> 3, w2_tile = (rank & 7) * 2 + grp;              // this group's FFN-out tile column (of 16)
+    unsigned char* w2_lds_base = smem_all + 2 * GLDS + 16 + (size_t)grp * (WBUF_REGS * 256 * 16);
+    if constexpr (W2_LDS_OK) {
+        if (w2_lds && w2_layer < a.Ld) {
+            WBuf park;
+            dec_gemm_prefetch<T, KWF, 16>(park, a.L[w2_layer].w2, D, w2_tile, tid, true);
+#pragma unroll
+            for (int c = 0; c < KWF; ++c) st16(w2_lds_base + ((size_t)c * 256 + tid) * 16, park.r[c]);
+        }
+    }
+
     int t = 0;
     for (; t < a.max_len; ++t) {
         gb.t_host = t;
@@ -213,7 +241,11 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 if (base_ > 0) __syncthreads();          /* the previous round's LDS reads are done */                  \
                 if (base_ + rank * 2 < nt_) {                                                                           \
                     const int tile_ = base_ + sb; const bool ok_ = tile_ < nt_; const int tc_ = ok_ ? tile_ : nt_ - 1;  \
-                    if (base_ == 0) dec_gemm_tile_pf<T, PRO, EPI, KW, BN, true, PRE>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts, wbuf, PF); \
+                    if (base_ == 0) {                                                                                   \
+                        auto args_ = ARGS;                                                                              \
+                        args_.stamps = (ts.stp && grp == 0) ? ts.stp + 5 - 3 * tc_ : nullptr;   /* tile stamps land at stp[5..7] */ \
+                        dec_gemm_tile_pf<T, PRO, EPI, KW, BN, true, PRE>(args_, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts, wbuf, PF); \
+                    }                                                                                                   \
                     else dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts);  \
                 } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
@@ -298,7 +330,30 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 DecGemmArgs<T> g = gb; g.N = 2 * F; g.K = D; g.W = W.w1; g.bias = W.b1; g.y = ly; g.x_out = lx; g.h_out = lhid; g.F = F;
                 PS_GEMM(PRO_LN2, EPI_GEGLU, KWP, 32, g, NC_F1, PF_P, pf_f2);
                 DecGemmArgs<T> h = gb; h.N = D; h.K = F; h.W = W.w2; h.bias = W.b2; h.A = lhid; h.resid = lx; h.y_out = ly;
-                PS_GEMM(PRO_NONE, EPI_BIAS_RES, KWF, 16, h, NC_F2, PF_F, pf_next);
+                bool w2_done = false;
+                if constexpr (W2_LDS_OK) {
+                    if (w2_lds) {                              // block-uniform
+                        w2_done = true;
+                        if (w2_layer == l) {
+                            WBuf wb;
+#pragma unroll
+                            for (int c = 0; c < KWF; ++c) wb.r[c] = ld16(w2_lds_base + ((size_t)c * 256 + tid) * 16);
+                            for (int by = 0; by < nrt; ++by) {
+                                if (by > 0) __syncthreads();
+                                auto args_ = h;
+                                args_.stamps = (ts.stp && grp == 0 && by == 0) ? ts.stp + 5 - 3 * w2_tile : nullptr;
+                                if (by == 0) dec_gemm_tile_pf<T, PRO_NONE, EPI_BIAS_RES, KWF, 16, true, true>(args_, w2_tile, by, tid, smem, true, ts, wb, pf_next);
+                                else dec_gemm_tile_pf<T, PRO_NONE, EPI_BIAS_RES, KWF, 16, true, true>(args_, w2_tile, by, tid, smem, true, ts, wb, none);
+                            }
+                        } else {
+                            ts(); pf_next();
+                        }
+                        ts();
+                        ts.arrive();
+                        ++stage;
+                    }
+                }
+                if (!w2_done) PS_GEMM(PRO_NONE, EPI_BIAS_RES, KWF, 16, h, NC_F2, PF_F, pf_next);
             }
             if (ts.dead) break;
         }
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const int j4 = base + u * 64 + lane;
-                            v[u] = ldc_f4<true>(lg + min(j4, n4 - 1) * 4);
+                            v[u] = ldc_f4_at<true>(a.dlogits, (size_t)row * a.V + (size_t)min(j4, n4 - 1) * 4);
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
@@ -347,12 +402,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                         if (v > best) { best = v; bi = j; }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }   // ties -> lowest index (torch.argmax)
-                }
+                wave_argmax(best, bi);                                        // ties -> lowest index (torch.argmax)
                 if (lane == 0) {
                     a.cur_tok[row] = bi;
                     a.tokens_out[(size_t)row * a.out_stride + t] = bi;

@@ -82,12 +82,7 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(StepArgs a) {
             if (v > best) { best = v; bi = j; }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }   // ties -> lowest index (torch.argmax)
-    }
+    wave_argmax(best, bi);                                                 // ties -> lowest index (torch.argmax)
     if (lane == 0) commit_token(a, row, t, bi);
 }
 
@@ -128,8 +123,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
         const unsigned cand = prefix | (1u << bit);
         int cnt = 0;
         for (int j = lane; j < V; j += 64) cnt += fkey(row_lds[j]) >= cand ? 1 : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+        cnt = wave_sum(cnt);
         if (cnt >= k) prefix = cand;
     }
     // kept set: keys > prefix, plus the first (k - n_greater) entries equal to it in index order (ties)
@@ -137,8 +131,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     int ngt = 0, neq = 0;
     for (int j = j0; j < j1; ++j) { const unsigned key = fkey(row_lds[j]); ngt += key > prefix; neq += key == prefix; }
     int ngt_all = ngt, eq_before = neq;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ngt_all += __shfl_xor(ngt_all, o, 64);
+    ngt_all = wave_sum(ngt_all);
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(eq_before, o, 64); if (lane >= o) eq_before += v; }
     eq_before -= neq;                                 // exclusive scan of the tie counts
@@ -173,11 +166,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max
         float best = -3.4e38f; int bi = 0x7fffffff;
         for (int j = lane; j < V; j += 64) { const float v = lg[j]; if (v > best) { best = v; bi = j; } }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
+        wave_argmax(best, bi);
         pick = bi;
     }
     if (lane == 0) commit_token(a, row, t, pick);
@@ -234,11 +223,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
             else c = s_score[j] + (lg[f] - s_lse[j]);
             if (c > best || (c == best && f < bi)) { best = c; bi = f; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
+        wave_argmax(best, bi);
         if (lane == 0) { red[wave] = best; redi[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
