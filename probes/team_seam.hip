@@ -16,6 +16,9 @@
 //       (plain store); the consumer's first wave reads the line with one sc1 load per poll (lane r = block r)
 //   F4  as F3, polled with SCALAR loads (s_load_dwordx16 ... glc: lgkmcnt, not vmcnt -- a polling wave could keep vector loads
 //       in flight)
+//   F5  no flag at all: every word travels as an 8-byte {value, stage} pair (the "LL" idea of the collective libraries);
+//       producers just store, no drain, no barrier, no publication; every consumer thread re-reads its own 16-byte pieces
+//       (sc1) until both stage tags match
 //   L   one launch per stage (grid = all teams), the structure the engine has today
 // Optional load: every LOADEVERY-th stage each block also streams STREAM_KB of a large buffer with non-temporal loads
 // (the cross-attention stage of the real step).
@@ -146,6 +149,60 @@ __global__ __launch_bounds__(512) void team_chain(Args a) {
     if (sink.x == 0x12345u && sink.y == 0x777u) a.fail[1] = sink.z + sink.w + dead;   // keep the stream alive
 }
 
+// F5: {value, tag} pairs, [teams][2][R][D] x 8 bytes
+__global__ __launch_bounds__(512) void team_chain_ll(Args a, uint2* act2) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[R * D];
+    const int team = blockIdx.x % a.teams, rank = blockIdx.x / a.teams;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    if (tid == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        a.xcc[blockIdx.x] = id & 0xf;
+    }
+    unsigned long long t0 = 0;
+    if (tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    u32x4 sink = {0, 0, 0, 0};
+    for (int s = 0; s < a.stages; ++s) {
+        const uint2* in = act2 + ((size_t)team * 2 + (s & 1)) * R * D;
+        uint2* out = act2 + ((size_t)team * 2 + ((s + 1) & 1)) * R * D;
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint2*>(in), 0, R * D * 8, 0x00020000);
+        // this thread's pieces: R*D/2 16-byte pieces (two pairs each) over nthr threads
+        constexpr int MAXP = 8;
+        u32x4 x[MAXP];
+        const int np = (R * D / 2 + nthr - 1) / nthr;
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) if (i < np) x[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, (tid + i * nthr) * 16, 0, 16);
+#pragma unroll
+            for (int i = 0; i < MAXP; ++i) if (i < np) ok = ok && x[i].y == (unsigned)s && x[i].w == (unsigned)s;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+            if (++spins > (1u << 22)) { if ((tid & 63) == 0) atomicAdd(a.fail, 1u); break; }
+        }
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) if (i < np) { const int v = tid + i * nthr; lds[2 * v] = x[i].x; lds[2 * v + 1] = x[i].z; }
+        if (a.stream_kb && a.load_every && (s % a.load_every) == a.load_every / 2) {
+            const int nvec = a.stream_kb * 64;
+            const size_t base = ((size_t)(blockIdx.x * 131 + s * 7919) * (size_t)nvec) % (a.big_vec - nvec);
+            for (int v = tid; v < nvec; v += nthr) {
+                const u32x4 y = __builtin_nontemporal_load(a.big + base + v);
+                sink.x ^= y.x; sink.y ^= y.y; sink.z ^= y.z; sink.w ^= y.w;
+            }
+        }
+        __syncthreads();
+        const int cols = D / a.S;
+        for (int e = tid; e < R * cols; e += nthr) {
+            const int r = e / cols, c = rank * cols + e % cols;
+            const uint32_t v = lds[r * D + (c + 1) % D] * 1664525u + lds[r * D + (c * 7 + 3) % D] + (uint32_t)s;
+            out[r * D + c] = make_uint2(v, (unsigned)(s + 1));
+        }
+        __syncthreads();                                                        // LDS reuse
+    }
+    if (tid == 0 && rank == 0) a.ticks[team] = __builtin_amdgcn_s_memrealtime() - t0;
+    if (sink.x == 0x12345u && sink.y == 0x777u) a.fail[1] = sink.z + sink.w;
+}
+
 // the same stage as its own launch: grid = teams * S blocks, in/out by stage parity
 __global__ __launch_bounds__(512) void stage_launch(Args a, int s) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[R * D];
@@ -169,7 +226,7 @@ int main(int argc, char** argv) {
     u32x4* big; hipMalloc(&big, big_bytes); hipMemset(big, 1, big_bytes);
     hipStream_t st; hipStreamCreate(&st);
     printf("form teams S thr stream_kb | us/stage (host) | in-kernel us/stage min..max | wrong words | spin fails | xcc spread per team\n");
-    for (int thr : {256, 512}) for (int S : {32, 64}) for (int stream_kb : {0, 300}) for (int form : {0, 1, 2, 3, 4, 5}) {
+    for (int thr : {256, 512}) for (int S : {32, 64}) for (int stream_kb : {0, 300}) for (int form : {0, 1, 2, 3, 4, 5, 6}) {
         const int teams = 8, blocks = teams * S;
         if (blocks * thr > 256 * 512 * 2) continue;
         if (thr == 512 && S == 64) continue;                                    // 512 blocks of 512 threads: not co-resident with headroom
@@ -177,6 +234,7 @@ int main(int argc, char** argv) {
         a.teams = teams; a.S = S; a.stages = stages; a.stream_kb = stream_kb; a.load_every = 7;
         a.big = big; a.big_vec = big_bytes / 16;
         hipMalloc(&a.act, (size_t)teams * 2 * R * D * 4);
+        uint2* act2; hipMalloc(&act2, (size_t)teams * 2 * R * D * 8);
         hipMalloc(&a.counter, teams * 32 * 4); hipMalloc(&a.flagline, teams * 64 * 4); hipMalloc(&a.fail, 64); hipMalloc(&a.xcc, blocks * 4); hipMalloc(&a.ticks, teams * 8);
         std::vector<uint32_t> init((size_t)teams * 2 * R * D);
         for (size_t i = 0; i < init.size(); ++i) init[i] = (uint32_t)(i * 2654435761u + 12345u);
@@ -184,6 +242,12 @@ int main(int argc, char** argv) {
         std::vector<unsigned> xcc(blocks);
         for (int rep = 0; rep < 6; ++rep) {
             hipMemcpy(a.act, init.data(), init.size() * 4, hipMemcpyHostToDevice);
+            if (form == 6) {
+                std::vector<uint2> i2(init.size());
+                for (size_t i = 0; i < init.size(); ++i) i2[i] = make_uint2(init[i], 0u);
+                for (int t = 0; t < teams; ++t) for (int i = 0; i < R * D; ++i) i2[((size_t)t * 2 + 1) * R * D + i].y = 0xffffffffu;
+                hipMemcpy(act2, i2.data(), i2.size() * 8, hipMemcpyHostToDevice);
+            }
             hipMemset(a.counter, 0, teams * 32 * 4); hipMemset(a.flagline, 0, teams * 64 * 4); hipMemset(a.fail, 0, 64); hipMemset(a.ticks, 0, teams * 8);
             hipDeviceSynchronize();
             auto t0 = std::chrono::high_resolution_clock::now();
@@ -192,6 +256,7 @@ int main(int argc, char** argv) {
             else if (form == 2) hipLaunchKernelGGL(team_chain<2>, dim3(blocks), dim3(thr), 0, st, a);
             else if (form == 4) hipLaunchKernelGGL(team_chain<3>, dim3(blocks), dim3(thr), 0, st, a);
             else if (form == 5) hipLaunchKernelGGL(team_chain<4>, dim3(blocks), dim3(thr), 0, st, a);
+            else if (form == 6) hipLaunchKernelGGL(team_chain_ll, dim3(blocks), dim3(thr), 0, st, a, act2);
             else for (int s = 0; s < stages; ++s) hipLaunchKernelGGL(stage_launch, dim3(blocks), dim3(thr), 0, st, a, s);
             hipError_t e = hipStreamSynchronize(st);
             const double us = std::chrono::duration<double, std::micro>(std::chrono::high_resolution_clock::now() - t0).count();
@@ -200,6 +265,11 @@ int main(int argc, char** argv) {
             best = std::min(best, us / stages);
             std::vector<uint32_t> got(init.size());
             hipMemcpy(got.data(), a.act, got.size() * 4, hipMemcpyDeviceToHost);
+            if (form == 6) {
+                std::vector<uint2> g2(init.size());
+                hipMemcpy(g2.data(), act2, g2.size() * 8, hipMemcpyDeviceToHost);
+                for (size_t i = 0; i < g2.size(); ++i) got[i] = g2[i].x;
+            }
             for (int t = 0; t < teams; ++t) {
                 std::vector<uint32_t> x(init.begin() + (size_t)t * 2 * R * D, init.begin() + (size_t)t * 2 * R * D + R * D);
                 host_ref(x, stages);
@@ -218,10 +288,10 @@ int main(int argc, char** argv) {
             int off = 0;
             for (int t = 0; t < teams; ++t) { unsigned m = 0; for (int b = t; b < blocks; b += teams) m |= 1u << xcc[b]; off += snprintf(spread + off, sizeof spread - off, "%d ", __builtin_popcount(m)); }
         }
-        printf("%s %d %2d %3d %3d | %7.2f | %6.2f .. %6.2f | %ld | %u | %s\n", form == 3 ? "L " : (form == 0 ? "F0" : form == 1 ? "F1" : form == 2 ? "F2" : form == 4 ? "F3" : "F4"),
+        printf("%s %d %2d %3d %3d | %7.2f | %6.2f .. %6.2f | %ld | %u | %s\n", form == 3 ? "L " : (form == 0 ? "F0" : form == 1 ? "F1" : form == 2 ? "F2" : form == 4 ? "F3" : form == 5 ? "F4" : "F5"),
                teams, S, thr, stream_kb, best, form != 3 ? kmin : 0.0, form != 3 ? kmax : 0.0, wrong, fails, spread);
         fflush(stdout);
-        hipFree(a.act); hipFree(a.counter); hipFree(a.flagline); hipFree(a.fail); hipFree(a.xcc); hipFree(a.ticks);
+        hipFree(act2); hipFree(a.act); hipFree(a.counter); hipFree(a.flagline); hipFree(a.fail); hipFree(a.xcc); hipFree(a.ticks);
     }
     return 0;
 }

@@ -163,7 +163,9 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = (COH || a.t_host >= 0) ? a.t_host : *a.t_ptr;
     // cached keys: fused self handles the new key t apart; plain self finds it in the cache already
     const int L = MODE == ATT_CROSS ? a.len : (FUSED ? t : t + 1);
-    const int Lm1 = max(L - 1, 0);
+    // valid = false (persistent kernel: a group without a tile keeps the workgroup's barriers): every panel address clamps
+    // to row 0, one cache line per wave instead of the whole panel
+    const int Lm1 = valid ? max(L - 1, 0) : 0;
     const int key0 = wave * KPI + kq;
     // byte-row address of key `key` in the K (or V) panel: own slot, or (beam) the slot recorded for that position
     const size_t slot_stride = (size_t)a.heads * a.lmax * DH;
@@ -201,7 +203,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         if (poll_wave) issue_k(0);
     } else if constexpr (HIST_EARLY) {
         const bool early = t > 0 && !poll_wave;                // the polling wave's wait would wait for its own panel too
-        clamp_row = max(t - 1, 0);
+        clamp_row = valid ? max(t - 1, 0) : 0;
         if (early) issue_k(0);
         wait_prev();
         if (!early) {

@@ -896,16 +896,16 @@ struct Engine : EngineBase {
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
     // Which decode path?  TXO_PERSIST=1 / 0 forces the persistent launch on / off (where it exists: decoder width 256 with 8
     // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
-    // 256 steps; profiles/r02_persist_ab.txt) -- bf16 with one (image, head) pair per 256-thread group, i.e. 16..64 images, or
-    // two full rounds (113..128 images): 1553 vs 1405 images/s at batch 64, 1999 vs 1924 at 128; other batch sizes leave
-    // groups idle in the attention stages (96 images: 1578 vs 1646), and the fp32 build of the kernel spills.
+    // 256 steps; profiles/r02_persist_ab.txt): bf16, 8..128 images (1711 vs 1472 images/s at batch 64, 2237 vs 2065 at 128).
     bool persist_usable(int B) const {
         if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
-        return sizeof(T) == 2 && D == 256 && ((B >= 16 && B <= 64) || (B > 112 && B <= 128));
+        // measured A/B (profiles/r02_persist_ab.txt): the persistent launch wins for 8 <= B <= 128 in bf16 (one or two 16-row
+        // tiles per team); B <= 4 is the graph-replayed launch path's, B > 128 (3+ row tiles per team) and fp32 are a wash or lose
+        return sizeof(T) == 2 && D == 256 && B >= 8 && B <= 128;
     }
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {

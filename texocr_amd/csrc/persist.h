@@ -153,7 +153,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
     unsigned char* smem = smem_all + (size_t)grp * GLDS;
     int* lds_dead = reinterpret_cast<int*>(smem_all + 2 * GLDS);
-    const int sb = rank * 2 + grp;                            // this group among the team's 64
+    const int sb = rank * 2 + grp;                            // this group among the team's 64 (GEMM tiles)
+    // attention tiles stream a K/V panel each (150 KB at 589 keys): they are dealt to the workgroups' FIRST groups before
+    // any second group gets one, so that a team with up to 32 tiles (batch 32) pulls them through 32 CUs instead of 16
+    const int sa = grp * PS_TEAM_BLOCKS + rank;
     constexpr int NSB = PS_TEAM_BLOCKS * 2;
 
     // rows of this team
@@ -258,8 +261,8 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             const int np_ = nr * HEADS;                                                                                 \
             for (int base_ = 0; base_ < np_; base_ += NSB) {                                                            \
                 if (base_ > 0) __syncthreads();                                                                         \
-                if (base_ + rank * 2 < np_) {                                                                           \
-                    const int p_ = base_ + sb; const bool ok_ = p_ < np_;                                               \
+                if (base_ + rank < np_) {                                                                               \
+                    const int p_ = base_ + sa; const bool ok_ = p_ < np_;                                               \
                     if (base_ == 0) dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid, \
                         *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts, PF);                           \
                     else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid,        \
