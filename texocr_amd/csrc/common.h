@@ -163,6 +163,10 @@ __device__ inline void wave_argmax(float& best, int& bi) {
     take(xor32(best), xor32(bi));
 }
 
+// one LayerNorm element from its row statistics: the row kernels (rows.h) and the GEMM epilogues that rebuild the residual
+// x = LN(y) on the fly (gemm_big.h: EpiGluRes / EpiBiasRes with stats) share this form, so both give the same bits
+__device__ inline float ln_apply(float y, float mean, float rstd, float g, float b) { const float t = y - mean; return t * rstd * g + b; }
+
 // exact-erf GELU (F.gelu default, reference attention.py:17) and sigmoid (nn.GLU, :98)
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ inline float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }

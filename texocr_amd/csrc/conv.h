@@ -73,12 +73,12 @@ struct EpiTokens {
         store8<float>(x + ((size_t)b * (hw + 1) + 1 + p) * D + n, v);
     }
     static constexpr bool HAS_ROW = true;
-    __device__ inline void cols(int n, float (&cb)[16]) const { load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); }
-    __device__ inline void rowop(int m, int n, float (&r)[8]) const {
+    __device__ inline void cols(int n, float (&cb)[32]) const { load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); }
+    __device__ inline void rowop(int m, int n, float (&r)[10]) const {
         const int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;
-        load8(pos + (size_t)(1 + pr * Gw + pc) * D + n, r);
+        load8(pos + (size_t)(1 + pr * Gw + pc) * D + n, reinterpret_cast<float (&)[8]>(r));
     }
-    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&r)[10], bool valid) const {
         const int b = m / hw, p = m - b * hw;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += cb[e] + r[e];

@@ -115,7 +115,7 @@ struct Engine : EngineBase {
     T* wlog = nullptr; float* blog = nullptr; T* wckv = nullptr;
     std::vector<AttnW> dec_self, dec_cross; std::vector<MlpW> dec_mlp;
     // ----- workspace -----
-    float *ex = nullptr, *ey = nullptr, *eqkv = nullptr, *eenc = nullptr; T *ez = nullptr, *eao = nullptr, *ehid = nullptr;
+    float *ex = nullptr, *ey = nullptr, *eqkv = nullptr, *eenc = nullptr, *estats = nullptr; T *ez = nullptr, *eao = nullptr, *ehid = nullptr;
     T* enc_t = nullptr;               // bf16 copy of the encoder output (A operand of the cross K/V GEMM)
     T *ckv = nullptr, *skv = nullptr;  // cross [Ld][2][B*h][N][64], self [Ld][2][B*h][Tmax][64]
     float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr, *dz = nullptr;
@@ -456,6 +456,7 @@ struct Engine : EngineBase {
             if (int r = dalloc(&gn_stats, (size_t)Bmax * 64)) return r;
         }
         if (int r = dalloc(&ex, M * D)) return r;
+        if (int r = dalloc(&estats, M * 2)) return r;
         if (int r = dalloc(&ey, M * D)) return r;
         if (int r = dalloc(&ez, M * D)) return r;
         if (int r = dalloc(&eenc, M * D)) return r;
@@ -588,8 +589,12 @@ struct Engine : EngineBase {
         }
         const size_t hs = (size_t)M * Ie;      // one of q/k/v, head-major [B*heads][N][64]
         for (int l = 0; l < cfg.enc_layers; ++l) {
+            // The stream between two sub-layers is x = LN(y) (the residual) and z = LN(x) (the block input), attention.py:242-259.
+            // x is never written: the row kernel leaves {mean, rstd} of LN(y) per row (rows.h MODE 3) and the next GEMM epilogue
+            // rebuilds its residual from y -- in place, ey is both its residual source and its output -- with the same expression.
+            const ResidLN res_x{ey, estats, enc_g, enc_b, D}, res_first{ex, nullptr, nullptr, nullptr, D};
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
-            else launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
+            else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
             const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);
             if constexpr (sizeof(T) == 4) {
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
@@ -604,10 +609,10 @@ struct Engine : EngineBase {
                 else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
-                               EpiGluRes<sizeof(T) == 2>{ey, ex, enc_attn[l].bo, D});
-            launch_ln<1, T>(s, ey, ex, ez, enc_g, enc_b, M);
+                               EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo});
+            launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
             gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
-            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, ex, enc_mlp[l].b2, D});
+            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2});
         }
         launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M);
         if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }

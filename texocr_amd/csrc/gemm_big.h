@@ -76,14 +76,14 @@ template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
     }
     // split form (gemm_pp.h): column operands once per lane, row operands batched ahead of the arithmetic, masked store
     static constexpr bool HAS_ROW = false;
-    __device__ inline void cols(int n, float (&cb)[16]) const {
+    __device__ inline void cols(int n, float (&cb)[32]) const {
         if (bias) load8(bias + n, reinterpret_cast<float (&)[8]>(cb));
         else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cb[e] = 0.f; }
     }
-    __device__ inline void rowop(int, int, float (&)[8]) const {}
-    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
+    __device__ inline void rowop(int, int, float (&)[10]) const {}
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&)[10], bool valid) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += cb[e];
         if (valid) store8<T>(out + (size_t)m * ldo + n, v);
@@ -98,32 +98,52 @@ template <typename T> struct EpiHeads {           // scatter n = (which, head, d
         store8<T>(base + which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d, v);
     }
     static constexpr bool HAS_ROW = false;
-    __device__ inline void cols(int, float (&)[16]) const {}
-    __device__ inline void rowop(int, int, float (&)[8]) const {}
-    __device__ inline void fin(int m, int n, float (&v)[8], const float (&)[16], const float (&)[8], bool valid) const {
+    __device__ inline void cols(int, float (&)[32]) const {}
+    __device__ inline void rowop(int, int, float (&)[10]) const {}
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&)[32], const float (&)[10], bool valid) const {
         if (valid) (*this)(m, n, v);
+    }
+};
+// Residual of the two encoder-side epilogues below: resid[m][j] itself (stats == nullptr), or -- the encoder's stream, where
+// x = LN(y) is never written (rows.h, MODE 3) -- rebuilt from the previous sub-layer's y and that row's {mean, rstd}:
+// x = ln_apply(y, mean, rstd, gamma[j], beta[j]), the very expression the row kernel normalises with.  `resid` may then be the
+// epilogue's own output buffer: every element is read and written by the same thread.
+struct ResidLN {
+    const float* resid; const float* stats; const float* gamma; const float* beta; int D;
+    __device__ inline void load(int m, int j, float (&r)[10]) const {
+        load8(resid + (size_t)m * D + j, reinterpret_cast<float (&)[8]>(r));
+        if (stats) { const float2 st = *reinterpret_cast<const float2*>(stats + (size_t)m * 2); r[8] = st.x; r[9] = st.y; }
+    }
+    // cg: gamma[j..j+7], beta[j..j+7] (loaded once per lane by cols())
+    __device__ inline void cols(int j, float (&cg)[16]) const {
+        if (stats) { load8(gamma + j, reinterpret_cast<float (&)[8]>(cg)); load8(beta + j, reinterpret_cast<float (&)[8]>(cg[8])); }
+    }
+    __device__ inline float value(const float (&r)[10], const float (&cg)[16], int e) const {
+        return stats ? ln_apply(r[e], r[8], r[9], cg[e], cg[8 + e]) : r[e];
     }
 };
 template <bool FAST = false>                      // FAST: perf mode (bf16 operands), see common.h
 struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoid(g+bg) + resid[m][j..]   (fp32 stream)
-    float* y; const float* resid; const float* bias; int D;   // bias is in the interleaved order
+    float* y; ResidLN res; const float* bias;     // bias is in the interleaved order
     static constexpr bool PAIRED = true;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
-        float bv[8], bg[8], r[8];
-        load8(bias + nv, bv); load8(bias + ng, bg); load8(resid + (size_t)m * D + j, r);
+        float bv[8], bg[8], r[10], cg[16];
+        load8(bias + nv, bv); load8(bias + ng, bg); res.load(m, j, r); res.cols(j, cg);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoid_sel<FAST>(g[e] + bg[e]) + r[e];
-        store8<float>(y + (size_t)m * D + j, v);
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoid_sel<FAST>(g[e] + bg[e]) + res.value(r, cg, e);
+        store8<float>(y + (size_t)m * res.D + j, v);
     }
     static constexpr bool HAS_ROW = true;
-    __device__ inline void cols(int nv, int ng, float (&cb)[16]) const {
+    __device__ inline void cols(int nv, int ng, float (&cb)[32]) const {
         load8(bias + nv, reinterpret_cast<float (&)[8]>(cb)); load8(bias + ng, reinterpret_cast<float (&)[8]>(cb[8]));
+        res.cols((nv >> 5) * 16 + (nv & 15), reinterpret_cast<float (&)[16]>(cb[16]));
     }
-    __device__ inline void rowop(int m, int j, float (&r)[8]) const { load8(resid + (size_t)m * D + j, r); }
-    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
+    __device__ inline void rowop(int m, int j, float (&r)[10]) const { res.load(m, j, r); }
+    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[32], const float (&r)[10], bool valid) const {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * sigmoid_sel<FAST>(g[e] + cb[8 + e]) + r[e];
-        if (valid) store8<float>(y + (size_t)m * D + j, v);
+        for (int e = 0; e < 8; ++e)
+            v[e] = (v[e] + cb[e]) * sigmoid_sel<FAST>(g[e] + cb[8 + e]) + res.value(r, reinterpret_cast<const float (&)[16]>(cb[16]), e);
+        if (valid) store8<float>(y + (size_t)m * res.D + j, v);
     }
 };
 template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
@@ -137,33 +157,35 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
         store8<T>(h + (size_t)m * F + j, v);
     }
     static constexpr bool HAS_ROW = false;
-    __device__ inline void cols(int nv, int ng, float (&cb)[16]) const {
+    __device__ inline void cols(int nv, int ng, float (&cb)[32]) const {
         load8(bias + nv, reinterpret_cast<float (&)[8]>(cb)); load8(bias + ng, reinterpret_cast<float (&)[8]>(cb[8]));
     }
-    __device__ inline void rowop(int, int, float (&)[8]) const {}
-    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
+    __device__ inline void rowop(int, int, float (&)[10]) const {}
+    __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[32], const float (&)[10], bool valid) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * gelu_sel<sizeof(T) == 2>(g[e] + cb[8 + e]);
         if (valid) store8<T>(h + (size_t)m * F + j, v);
     }
 };
 struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
-    float* y; const float* resid; const float* bias; int D;
+    float* y; ResidLN res; const float* bias;
     static constexpr bool PAIRED = false;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
-        float b[8], r[8];
-        load8(bias + n, b); load8(resid + (size_t)m * D + n, r);
+        float b[8], r[10], cg[16];
+        load8(bias + n, b); res.load(m, n, r); res.cols(n, cg);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += b[e] + r[e];
-        store8<float>(y + (size_t)m * D + n, v);
+        for (int e = 0; e < 8; ++e) v[e] += b[e] + res.value(r, cg, e);
+        store8<float>(y + (size_t)m * res.D + n, v);
     }
     static constexpr bool HAS_ROW = true;
-    __device__ inline void cols(int n, float (&cb)[16]) const { load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); }
-    __device__ inline void rowop(int m, int n, float (&r)[8]) const { load8(resid + (size_t)m * D + n, r); }
-    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&r)[8], bool valid) const {
+    __device__ inline void cols(int n, float (&cb)[32]) const {
+        load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); res.cols(n, reinterpret_cast<float (&)[16]>(cb[16]));
+    }
+    __device__ inline void rowop(int m, int n, float (&r)[10]) const { res.load(m, n, r); }
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&r)[10], bool valid) const {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += cb[e] + r[e];
-        if (valid) store8<float>(y + (size_t)m * D + n, v);
+        for (int e = 0; e < 8; ++e) v[e] += cb[e] + res.value(r, reinterpret_cast<const float (&)[16]>(cb[16]), e);
+        if (valid) store8<float>(y + (size_t)m * res.D + n, v);
     }
 };
 struct EpiPatch {                                 // x[b][1+p][n..] = acc + bias + pos[1 + pr*G + pc][n..]

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
         {
             int m0, n0; tile_origin(seq, m0, n0);
             const int nbase = n0 + wc * 64;
-            float cb[16];
+            float cb[32];
             int cv, nv;                                                   // paired: value columns of this lane; plain: its 8 columns
             if constexpr (Epi::PAIRED) {
                 const int vg = lane & 3;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
 #pragma unroll
             for (int i = 0; i < 8; ++i) {                                 // row tile i of the wave: 16 rows x 64 columns
                 const int mbase = m0 + wr * 128 + i * 16;
-                float rr[ITEMS][8];
+                float rr[ITEMS][10];
                 if constexpr (Epi::HAS_ROW) {
 #pragma unroll
                     for (int q = 0; q < ITEMS; ++q) epi.rowop(min(mbase + (lane >> RSHIFT) + RSTEP * q, M - 1), jout, rr[q]);

@@ -13,8 +13,10 @@
 namespace txo {
 
 // LN of a row held as NV float4 per lane (row length D = NV * 256); returns normalised values in place.
+// mean_out / rstd_out: the row statistics, for consumers that rebuild the normalised row themselves (ln_apply)
 template <int NV>
-__device__ inline void ln_row(float4 (&v)[NV], const float4 (&g)[NV], const float4 (&b)[NV], float inv_d) {
+__device__ inline void ln_row(float4 (&v)[NV], const float4 (&g)[NV], const float4 (&b)[NV], float inv_d, float* mean_out = nullptr,
+                              float* rstd_out = nullptr) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -22,15 +24,16 @@ __device__ inline void ln_row(float4 (&v)[NV], const float4 (&g)[NV], const floa
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
-        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        const float tx = v[i].x - mean, ty = v[i].y - mean, tz = v[i].z - mean, tw = v[i].w - mean;
+        q += (tx * tx + ty * ty) + (tz * tz + tw * tw);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
-        v[i].z = v[i].z * rstd * g[i].z + b[i].z; v[i].w = v[i].w * rstd * g[i].w + b[i].w;
+        v[i].x = ln_apply(v[i].x, mean, rstd, g[i].x, b[i].x); v[i].y = ln_apply(v[i].y, mean, rstd, g[i].y, b[i].y);
+        v[i].z = ln_apply(v[i].z, mean, rstd, g[i].z, b[i].z); v[i].w = ln_apply(v[i].w, mean, rstd, g[i].w, b[i].w);
     }
+    if (mean_out) { *mean_out = mean; *rstd_out = rstd; }
 }
 
 template <typename T>
@@ -46,6 +49,9 @@ template <> __device__ inline void store4<bf16>(bf16* p, const float4& v) {
 // MODE 0: x given      -> z = LN(x)                       (first sub-layer of a stack)
 // MODE 1: y given      -> x = LN(y) (written), z = LN(x)  (between sub-layers)
 // MODE 2: y given      -> z = LN_final(y)                 (after the stack; separate gamma/beta)
+// MODE 3: y given      -> stats[row] = {mean, rstd} of LN(y) (written where MODE 1 writes x), z = LN(LN(y)): the encoder's form --
+//         x itself is never materialised, the next GEMM epilogue rebuilds its residual from y and the statistics (ln_apply):
+//         a third of this kernel's bytes (it is HBM-bound) and an M x D fp32 write less per sub-layer
 template <typename T, int NV, int MODE>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ in, float* __restrict__ x_out,
                                                       T* __restrict__ z_out, const float* __restrict__ gamma,
@@ -63,11 +69,18 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
         g[i] = *reinterpret_cast<const float4*>(gamma + c);
         b[i] = *reinterpret_cast<const float4*>(beta + c);
     }
-    ln_row<NV>(v, g, b, inv_d);
-    if constexpr (MODE == 1) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(x_out + (size_t)row * D + i * 256 + lane * 4) = v[i];
+    if constexpr (MODE == 3) {
+        float mean, rstd;
+        ln_row<NV>(v, g, b, inv_d, &mean, &rstd);
+        if (lane == 0) *reinterpret_cast<float2*>(x_out + (size_t)row * 2) = make_float2(mean, rstd);
         ln_row<NV>(v, g, b, inv_d);
+    } else {
+        ln_row<NV>(v, g, b, inv_d);
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) *reinterpret_cast<float4*>(x_out + (size_t)row * D + i * 256 + lane * 4) = v[i];
+            ln_row<NV>(v, g, b, inv_d);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NV; ++i) store4<T>(z_out + (size_t)row * D + i * 256 + lane * 4, v[i]);
@@ -83,6 +96,24 @@ __global__ __launch_bounds__(256) void ln_rows_generic_kernel(const float* __res
     if (row >= rows) return;
     const float inv_d = 1.0f / D;
     const float* src = in + (size_t)row * D;
+    if constexpr (MODE == 3) {                        // statistics of LN(y) out, x = LN(y) rebuilt per use, z = LN(x)
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += src[c];
+        const float mean = wave_sum(s) * inv_d;
+        float q = 0.f;
+        for (int c = lane; c < D; c += 64) { const float d = src[c] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
+        if (lane == 0) *reinterpret_cast<float2*>(x_out + (size_t)row * 2) = make_float2(mean, rstd);
+        float s2 = 0.f;
+        for (int c = lane; c < D; c += 64) s2 += ln_apply(src[c], mean, rstd, gamma[c], beta[c]);
+        const float mean2 = wave_sum(s2) * inv_d;
+        float q2 = 0.f;
+        for (int c = lane; c < D; c += 64) { const float d = ln_apply(src[c], mean, rstd, gamma[c], beta[c]) - mean2; q2 += d * d; }
+        const float rstd2 = 1.0f / sqrtf(wave_sum(q2) * inv_d + LN_EPS);
+        for (int c = lane; c < D; c += 64)
+            z_out[(size_t)row * D + c] = Elem<T>::from_f32(ln_apply(ln_apply(src[c], mean, rstd, gamma[c], beta[c]), mean2, rstd2, gamma[c], beta[c]));
+        return;
+    }
     for (int pass = 0; pass < (MODE == 1 ? 2 : 1); ++pass) {
         float s = 0.f;
         for (int c = lane; c < D; c += 64) s += src[c];
@@ -92,7 +123,7 @@ __global__ __launch_bounds__(256) void ln_rows_generic_kernel(const float* __res
         const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
         const bool to_x = (MODE == 1 && pass == 0);
         for (int c = lane; c < D; c += 64) {
-            const float o = (src[c] - mean) * rstd * gamma[c] + beta[c];
+            const float o = ln_apply(src[c], mean, rstd, gamma[c], beta[c]);
             if (to_x) x_out[(size_t)row * D + c] = o;
             else z_out[(size_t)row * D + c] = Elem<T>::from_f32(o);
         }
