@@ -11,11 +11,11 @@ template <typename T> struct EpiNull {            // no stores (unless a value i
     T* out; int ldo; const float* bias;
     static constexpr bool PAIRED = false;
     static constexpr bool HAS_ROW = false;
-    __device__ inline void cols(int n, float (&cb)[16]) const {
+    __device__ inline void cols(int n, float (&cb)[32]) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cb[e] = 0.f; }
-    __device__ inline void rowop(int, int, float (&)[8]) const {}
-    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[16], const float (&)[8], bool valid) const {
+    __device__ inline void rowop(int, int, float (&)[10]) const {}
+    __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&)[10], bool valid) const {
         if (valid && v[0] == 12345.678f) store8<T>(out + (size_t)m * ldo + n, v);
     }
 };

@@ -109,7 +109,7 @@ struct Engine : EngineBase {
     T* stem_w = nullptr; GnW stem_gn; std::vector<BlockW> blocks;
     T* act[4] = {nullptr, nullptr, nullptr, nullptr}; float *gn_partial = nullptr, *gn_stats = nullptr;
     bool hybrid = false;
-    float *enc_g = nullptr, *enc_b = nullptr, *encn_g = nullptr, *encn_b = nullptr;
+    float *enc_g = nullptr, *enc_b = nullptr, *encn_g = nullptr, *encn_b = nullptr, *enc_gb = nullptr;   // enc_gb: gamma then beta (GEMM epilogues)
     std::vector<AttnW> enc_attn; std::vector<MlpW> enc_mlp;
     float *tok_emb = nullptr, *pos_emb = nullptr, *dec_g = nullptr, *dec_b = nullptr, *decn_g = nullptr, *decn_b = nullptr;
     T* wlog = nullptr; float* blog = nullptr; T* wckv = nullptr;
@@ -383,6 +383,12 @@ struct Engine : EngineBase {
         if (!(t = get("encoder.patch_embed.proj.bias", {D}))) return TXO_E_STATE;
         if (int r = upload_f32(&patch_b, t->data)) return r;
         if (int r = shared_ln("encoder.attn_layers", 2 * c.enc_layers, &enc_g, &enc_b)) return r;
+        {
+            std::vector<float> gb(get("encoder.attn_layers.layers.0.0.weight", {D})->data);
+            const std::vector<float>& bb = get("encoder.attn_layers.layers.0.0.bias", {D})->data;
+            gb.insert(gb.end(), bb.begin(), bb.end());
+            if (int r = upload_f32(&enc_gb, gb)) return r;
+        }
         enc_attn.resize(c.enc_layers); enc_mlp.resize(c.enc_layers);
         for (int l = 0; l < c.enc_layers; ++l) {
             const std::string p = "encoder.attn_layers.layers.";
@@ -592,7 +598,7 @@ struct Engine : EngineBase {
             // The stream between two sub-layers is x = LN(y) (the residual) and z = LN(x) (the block input), attention.py:242-259.
             // x is never written: the row kernel leaves {mean, rstd} of LN(y) per row (rows.h MODE 3) and the next GEMM epilogue
             // rebuilds its residual from y -- in place, ey is both its residual source and its output -- with the same expression.
-            const ResidLN res_x{ey, estats, enc_g, enc_b, D}, res_first{ex, nullptr, nullptr, nullptr, D};
+            const ResidLN res_x{ey, estats, enc_gb, D}, res_first{ex, nullptr, nullptr, D};
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
             else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
             const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);

@@ -109,14 +109,14 @@ template <typename T> struct EpiHeads {           // scatter n = (which, head, d
 // x = ln_apply(y, mean, rstd, gamma[j], beta[j]), the very expression the row kernel normalises with.  `resid` may then be the
 // epilogue's own output buffer: every element is read and written by the same thread.
 struct ResidLN {
-    const float* resid; const float* stats; const float* gamma; const float* beta; int D;
+    const float* resid; const float* stats; const float* gb; int D;     // gb: gamma[D] followed by beta[D]
     __device__ inline void load(int m, int j, float (&r)[10]) const {
         load8(resid + (size_t)m * D + j, reinterpret_cast<float (&)[8]>(r));
         if (stats) { const float2 st = *reinterpret_cast<const float2*>(stats + (size_t)m * 2); r[8] = st.x; r[9] = st.y; }
     }
     // cg: gamma[j..j+7], beta[j..j+7] (loaded once per lane by cols())
     __device__ inline void cols(int j, float (&cg)[16]) const {
-        if (stats) { load8(gamma + j, reinterpret_cast<float (&)[8]>(cg)); load8(beta + j, reinterpret_cast<float (&)[8]>(cg[8])); }
+        if (stats) { load8(gb + j, reinterpret_cast<float (&)[8]>(cg)); load8(gb + D + j, reinterpret_cast<float (&)[8]>(cg[8])); }
     }
     __device__ inline float value(const float (&r)[10], const float (&cg)[16], int e) const {
         return stats ? ln_apply(r[e], r[8], r[9], cg[e], cg[8 + e]) : r[e];

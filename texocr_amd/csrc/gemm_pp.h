@@ -81,32 +81,26 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
     // The A stream and the W stream run ahead of the MFMAs by different distances, so each keeps the offsets of the tile
     // it is currently fetching for.
     const int drow = lane >> 3, dslot = lane & 7;
-    int aoff[2][2], woff[2][2];
+    // The four instructions of a tile cover rows +0 / +64 / +128 / +192 from the lane's first row, and every one of those rows has
+    // the same (row & 7), hence the same swizzled piece.  W needs ONE per-lane offset (the others are uniform multiples of K
+    // further); A keeps four because its rows clamp to M - 1 in the last row panel.  (Eight precomputed offsets were long-lived
+    // VGPRs in a kernel at the 256-register limit: with the larger residual epilogues hipcc spilled them and reloaded them from
+    // scratch at every DMA issue -- vector-memory loads in the middle of the counted-vmcnt pipeline.)
+    const int dswz = (dslot ^ (drow & 7)) * 8;
+    int aoff[2][2], woff0 = 0;
     auto set_aoff = [&](int seq) {
         int m0, n0; tile_origin(seq, m0, n0);
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = x * 128 + j * 64 + wave * 8 + drow;
-                aoff[x][j] = min(m0 + row, M - 1) * K + (dslot ^ (row & 7)) * 8;
-            }
+            for (int j = 0; j < 2; ++j) aoff[x][j] = min(m0 + x * 128 + j * 64 + wave * 8 + drow, M - 1) * K + dswz;
     };
-    auto set_woff = [&](int seq) {
-        int m0, n0; tile_origin(seq, m0, n0);
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = x * 128 + j * 64 + wave * 8 + drow;
-                woff[x][j] = (n0 + row) * K + (dslot ^ (row & 7)) * 8;
-            }
-    };
+    auto set_woff = [&](int seq) { int m0, n0; tile_origin(seq, m0, n0); woff0 = (n0 + wave * 8 + drow) * K + dswz; };
     // half-tile x of operand `op` (0 = A, 1 = W), K tile kt of the stream's current tile -> buffer buf
     auto issue_half = [&](int op, int x, int kt, int buf) {
         unsigned char* base = lds + buf * PP_BUF_BYTES + op * PP_TILE_BYTES + x * (PP_TILE_BYTES / 2) + wave * 8 * 128;
         const bf16* src = op ? W : A;
-        const int o0 = op ? woff[x][0] : aoff[x][0], o1 = op ? woff[x][1] : aoff[x][1];
+        const int o0 = op ? woff0 + x * 128 * K : aoff[x][0], o1 = op ? woff0 + (x * 128 + 64) * K : aoff[x][1];
         dma16(src + o0 + kt * PP_BK, base);
         dma16(src + o1 + kt * PP_BK, base + 64 * 128);
     };
@@ -249,6 +243,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // reads done before the next row tile overwrites the region
+                // keep the row tiles' residual loads from being hoisted over one another (8 x 20 registers: the kernel is at 256)
+                if constexpr (Epi::HAS_ROW) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
