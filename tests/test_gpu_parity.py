@@ -701,6 +701,37 @@ def test_persistent_decode_bit_identical_to_launches(dtype, B):
     assert torch.equal(lp, ll)
 
 
+def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
+    """The persistent launch waits on other workgroups with bounded spins; when a hand-off times out (or a team turns out to
+    span two XCDs) every workgroup leaves, the engine reports it and redoes the decode with launches.  A test hook makes
+    team 0 report a time-out at position 3: same tokens and logits as the launch path, one fallback counted."""
+    import os
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=5, dtype="bf16", max_batch=16)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    img = torch.rand((16, 3, 64, 224), generator=g, device="cuda")
+    os.environ["TXO_PERSIST"] = "0"
+    try:
+        tl, ll = m.generate(img, 24, return_logits=True)
+    finally:
+        os.environ.pop("TXO_PERSIST")
+    before = m._engine.query(1)
+    os.environ["TXO_PERSIST"] = "1"; os.environ["TXO_PERSIST_INJECT_FAIL"] = "3"
+    try:
+        tp, lp = m.generate(img, 24, return_logits=True)
+    finally:
+        os.environ.pop("TXO_PERSIST"); os.environ.pop("TXO_PERSIST_INJECT_FAIL")
+    assert m._engine.query(1) == before + 1, "the injected time-out was not counted as a fallback"
+    assert m._engine.query(0) == 0, "the fallback decode must be the launch path"
+    assert torch.equal(tp, tl) and torch.equal(lp, ll)
+    os.environ["TXO_PERSIST"] = "1"
+    try:
+        tp2, _ = m.generate(img, 24, return_logits=True)     # and the engine is usable afterwards, persistent again
+    finally:
+        os.environ.pop("TXO_PERSIST")
+    assert m._engine.query(0) == 1 and torch.equal(tp2, tl)
+
+
 def test_persistent_decode_global_eos_break():
     """Small vocabulary so that eos fires at different positions in different rows and teams: the persistent launch must
     return exactly the columns of the reference's GLOBAL break (decoder.py:115-116), like the launch path and the oracle."""

@@ -67,6 +67,7 @@ template <typename T> struct PersistArgs {
     T *skv, *ckv; size_t self_stride, cross_stride;           // per (layer, k|v) plane
     int64_t* tokens_out; int out_stride; float* logits_out;
     PersistCtl* ctl;
+    int inject_fail;                                          // test hook: position at which team 0 reports a hand-off time-out (0 = never)
     int stagger_ticks;                                        // experiment: team k starts k * this many 10-ns ticks late (desynchronises the teams' HBM phases)
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
 };
@@ -232,6 +233,12 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     int t = 0;
     for (; t < a.max_len; ++t) {
         gb.t_host = t;
+        if (a.inject_fail > 0 && t == a.inject_fail && team == 0 && rank == 0) {   // TXO_PERSIST_INJECT_FAIL (tests): what a time-out does
+            if (threadIdx.x == 0) { atomicOr(&ctl->fail, 1u); *lds_dead = 1; }
+            __syncthreads();
+            ts.dead = true;
+            break;
+        }
         int stage = 0;
         ts.stp = (stamp_base && t == a.stamp_step) ? stamp_base : nullptr;
         // one GEMM stage: tiles (bx, by) dealt over the team's groups; a workgroup with no tile only synchronises.
