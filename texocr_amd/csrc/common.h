@@ -163,6 +163,12 @@ __device__ inline void wave_argmax(float& best, int& bi) {
     take(xor32(best), xor32(bi));
 }
 
+// 1 / sqrt(x): IEEE sqrt and division in the fp32 parity mode; perf mode (bf16 operands) takes v_rsq_f32 (1 ulp) -- the decode
+// step evaluates ~25 LayerNorms per position on its critical path, and the exact form is a chain of ~25 dependent instructions
+template <bool FAST> __device__ inline float rsqrt_sel(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_rsqf(x); else return 1.0f / sqrtf(x);
+}
+
 // one LayerNorm element from its row statistics: the row kernels (rows.h) and the GEMM epilogues that rebuild the residual
 // x = LN(y) on the fly (gemm_big.h: EpiGluRes / EpiBiasRes with stats) share this form, so both give the same bits
 __device__ inline float ln_apply(float y, float mean, float rstd, float g, float b) { const float t = y - mean; return t * rstd * g + b; }

@@ -68,7 +68,7 @@ __device__ inline void unpack16(const u32x4& raw, float (&f)[PER16]) {
     }
 }
 
-template <int NVMAX>
+template <int NVMAX, bool FAST>
 __device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX], const float4 (&b)[NVMAX], float inv_d) {
     float s = 0.f;
 #pragma unroll
@@ -80,7 +80,7 @@ __device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX]
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
+    const float rstd = rsqrt_sel<FAST>(wave_sum(q) * inv_d + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) if (i < nv) {
         v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
@@ -239,13 +239,13 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
                     v[i] = ldc_f4_at<COH>(a.y, (size_t)img * D + c);
                 }
             }
-            if constexpr (APRO == APRO_LN2) ln64<NVMAX>(v, nv, g, b, inv_d);
+            if constexpr (APRO == APRO_LN2) ln64<NVMAX, sizeof(T) == 2>(v, nv, g, b, inv_d);
             if (head == 0 && valid) {
 #pragma unroll
                 for (int i = 0; i < NVMAX; ++i) if (i < nv)
                     *reinterpret_cast<float4*>(a.x_out + (size_t)img * D + i * 256 + lane * 4) = v[i];
             }
-            ln64<NVMAX>(v, nv, g, b, inv_d);
+            ln64<NVMAX, sizeof(T) == 2>(v, nv, g, b, inv_d);
 #pragma unroll
             for (int i = 0; i < NVMAX; ++i) if (i < nv) *reinterpret_cast<float4*>(&zs[i * 256 + lane * 4]) = v[i];
         } else {
@@ -268,7 +268,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
                 float q = 0.f;
 #pragma unroll
                 for (int i = 0; i < 12; ++i) if (i < ne) { const float dl = (i * 64 + lane < D) ? vals[i] - mean : 0.f; q += dl * dl; }
-                const float rstd = 1.0f / sqrtf(wave_sum(q) * inv_d + LN_EPS);
+                const float rstd = rsqrt_sel<sizeof(T) == 2>(wave_sum(q) * inv_d + LN_EPS);
 #pragma unroll
                 for (int i = 0; i < 12; ++i) if (i < ne) {
                     const int c = i * 64 + lane;
@@ -349,8 +349,13 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     auto do_pass = [&](int base, int slot) {
         float sc[NL];
         float mx = -3.0e38f;
+        // self attention: slots (KPB keys each) wholly past the history are skipped by a wave-uniform branch -- their scores
+        // would be masked to -3e38 and their probabilities exactly 0, so nothing changes but the time (half the slots on average).
+        // Only where K and V are both in registers already (V_EARLY): a branch around a load costs hipcc's counted waits.
+        const int nslot = V_EARLY ? (L - base + KPB - 1) / KPB : NL;
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
+            if (V_EARLY && u >= nslot) { sc[u] = -3.0e38f; continue; }
             const int key = base + u * KPB + key0;
             float kf[PER16];
             if constexpr (HIST_EARLY) {
@@ -385,6 +390,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         for (int e = 0; e < PER16; ++e) acc[e] *= alpha;
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
+            if (V_EARLY && u >= nslot) continue;
             const float p = expf(sc[u] - m_new);              // masked keys: exp(-3e38 - m) == 0 exactly
             l_run = fmaf(p, count_me, l_run);
             float vf[PER16];

@@ -108,7 +108,7 @@ template <typename T> struct DecGemmArgs {
 constexpr int DG_BM = 16, DG_BN = 32, DG_GROUP = 8;   // DG_GROUP: k-chunks a wave keeps in flight at once
 
 // LN over a row spread across 16 lanes, NVMAX float4 per lane (row length 64*nv), gamma/beta in registers
-template <int NVMAX>
+template <int NVMAX, bool FAST>
 __device__ inline void ln16(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX], const float4 (&b)[NVMAX], float inv_d) {
     float s = 0.f;
 #pragma unroll
@@ -120,7 +120,7 @@ __device__ inline void ln16(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX]
         v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
-    const float rstd = 1.0f / sqrtf(row16_sum(q) * inv_d + LN_EPS);
+    const float rstd = rsqrt_sel<FAST>(row16_sum(q) * inv_d + LN_EPS);
 #pragma unroll
     for (int i = 0; i < NVMAX; ++i) if (i < nv) {
         v[i].x = v[i].x * rstd * g[i].x + b[i].x; v[i].y = v[i].y * rstd * g[i].y + b[i].y;
@@ -278,7 +278,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
                 v[i] = ldc_f4_at<COH>(a.y, (size_t)m * K + i * 64 + sub * 4);
         }
         pf();
-        if constexpr (PRO == PRO_LN2) ln16<NVMAX>(v, nv, g, b, inv_d);
+        if constexpr (PRO == PRO_LN2) ln16<NVMAX, sizeof(T) == 2>(v, nv, g, b, inv_d);
         if constexpr (PRO == PRO_EMBED || PRO == PRO_LN2) {
             if (bx == 0 && valid && m0 + r < rows) {
 #pragma unroll
@@ -286,7 +286,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
                     *reinterpret_cast<float4*>(a.x_out + (size_t)m * K + i * 64 + sub * 4) = v[i];
             }
         }
-        ln16<NVMAX>(v, nv, g, b, inv_d);
+        ln16<NVMAX, sizeof(T) == 2>(v, nv, g, b, inv_d);
 #pragma unroll
         for (int i = 0; i < NVMAX; ++i) if (i < nv) {
             unsigned char* dst = smem + a_off<T>(r, i * 64 + sub * 4, row_bytes, pmask);
