@@ -317,8 +317,10 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
 
     // ------------------------------ cross-wave K reduction through LDS ------------------------------
     if (a.stamps) { asm volatile("" :: "v"(acc0[0]), "v"(acc1[0])); ts1 = __builtin_amdgcn_s_memrealtime(); }
-    __syncthreads();                                          // everyone is done reading the A image
-    float* red = reinterpret_cast<float*>(smem);              // [wave][half][reg][lane]
+    // partial sums go BEHIND the A image (LN-prologue tiles) so that no barrier is needed between the last fragment read and
+    // the first partial-sum write; without an A image `smem` is idle here (its previous readers finished before this tile's
+    // wait_prev / the caller's round barrier)
+    float* red = reinterpret_cast<float*>(smem + (PRO != PRO_NONE ? DG_BM * row_bytes : 0));   // [wave][half][reg][lane]
 #pragma unroll
     for (int r = 0; r < 4; ++r) { red[((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[r];
                                   red[((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[r]; }
@@ -384,7 +386,7 @@ template <typename T>
 inline size_t dec_gemm_lds_bytes(int K, bool has_pro) {
     const size_t red = (size_t)4 * 2 * 4 * 64 * 4;
     const size_t img = has_pro ? (size_t)DG_BM * K * sizeof(T) : 0;
-    return red > img ? red : img;
+    return img + red;                                         // the partial sums sit behind the A image
 }
 
 }  // namespace txo

@@ -953,6 +953,8 @@ struct Engine : EngineBase {
         const char* stamp_file = getenv("TXO_PSTAMPS");
         pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
         if (const char* sg = getenv("TXO_PS_STAGGER_US")) pa.stagger_ticks = (int)(atof(sg) * 100.0);
+        pa.poll_sleep = 1;
+        if (const char* ps = getenv("TXO_PS_POLL_SLEEP")) pa.poll_sleep = atoi(ps);
         if (const char* inj = getenv("TXO_PERSIST_INJECT_FAIL")) pa.inject_fail = atoi(inj);   // tests: the give-up / fall-back path
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
         if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));

@@ -67,6 +67,7 @@ template <typename T> struct PersistArgs {
     T *skv, *ckv; size_t self_stride, cross_stride;           // per (layer, k|v) plane
     int64_t* tokens_out; int out_stride; float* logits_out;
     PersistCtl* ctl;
+    int poll_sleep;                                           // TeamSync: 64-clock sleeps between two polls of the flag line
     int inject_fail;                                          // test hook: position at which team 0 reports a hand-off time-out (0 = never)
     int stagger_ticks;                                        // experiment: team k starts k * this many 10-ns ticks late (desynchronises the teams' HBM phases)
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
@@ -82,6 +83,7 @@ struct TeamSync {
     unsigned* flags;                                          // this team's line: PS_TEAM_BLOCKS words
     int rank; unsigned epoch;                                 // stages this workgroup has finished
     unsigned* fail; int* lds_dead; bool armed, dead;
+    int poll_sleep;                                           // s_sleep(1) units (64 clocks) between two polls
     unsigned long long* stp;                                  // diagnostic: 5 ticks per stage (wait begin / end, drain begin / end, published)
     __device__ inline void operator()() {                     // wait until every workgroup of the team has finished the previous stage
         if (!armed) return;
@@ -90,10 +92,12 @@ struct TeamSync {
             if (stp && threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
             const int lane = threadIdx.x;
             unsigned spins = 0;
+            // ONE poll in flight.  (Four, a quarter of a round trip apart, to see the last arrival sooner: 37.2 vs 36.5 ms per
+            // generate -- the extra reads of the line queue in front of the arrivals' stores at its L2 channel.)
             for (;;) {
                 const unsigned v = lane < PS_TEAM_BLOCKS ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
                 if (__builtin_amdgcn_ballot_w64(v < epoch) == 0ull) break;
-                __builtin_amdgcn_s_sleep(1);
+                for (int i = 0; i < poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
                 if ((++spins & 1023u) == 0u) {                // ~ every 0.3 ms: give up after ~80 ms or when another workgroup has
                     if (spins > (1u << 18) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                         if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
@@ -129,8 +133,7 @@ template <typename T> constexpr int ps_kw_half(int K) {
 
 template <typename T, int D_, int HEADS_>
 constexpr size_t persist_group_lds() {
-    size_t g = (size_t)DG_BM * D_ * sizeof(T);                // LN-prologue A image (K = D)
-    if (g < 8192) g = 8192;                                   // cross-wave K reduction
+    size_t g = (size_t)DG_BM * D_ * sizeof(T) + 8192;         // LN-prologue A image (K = D) + the cross-wave K reduction behind it
     if (g < sizeof(DecAttnLds<false>)) g = sizeof(DecAttnLds<false>);
     return (g + 255) & ~(size_t)255;
 }
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         while (__builtin_amdgcn_s_memrealtime() - t0 < until) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
-    TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, nullptr};
+    TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, a.poll_sleep, nullptr};
     bool placement_checked = false;
 
     DecGemmArgs<T> gb{};
