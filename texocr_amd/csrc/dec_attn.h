@@ -95,6 +95,16 @@ __device__ inline void ln64(float4 (&v)[NVMAX], int nv, const float4 (&g)[NVMAX]
 // The hot loops are written WITHOUT data-dependent branches (clamped unconditional loads, masked scores of
 // -3e38 whose exp is exactly 0, selects): a guarded load becomes its own basic block and hipcc's waitcnt
 // insertion then falls back to vmcnt(0) per iteration, which serialises the whole K/V stream.
+// cross attention: wave-instructions of K (then V) per pass; the launch path and the persistent kernel must agree (same passes ->
+// same bits).  10 = 320 keys (bf16) per pass, two passes at 589 keys.  One pass of 20 kept the whole panel in flight but held 160
+// VGPRs of it: the persistent kernel (256-VGPR cap, both attention variants inlined) spilled around it and a CU ran two blocks of
+// the launch kernel at most.  Measured (same box, ms per generate): batch 64 persistent 36.4 -> 33.5, batch 256 launches 101.4 -> 98.8;
+// 7 and 5 are within noise of 10.
+#ifndef TXO_NL_CROSS
+#define TXO_NL_CROSS 10
+#endif
+constexpr int DA_NL_CROSS = TXO_NL_CROSS;
+
 // LDS of one 256-thread group
 template <bool BEAM> struct DecAttnLds {
     __attribute__((aligned(16))) float zs[768];   // normalised row
@@ -407,7 +417,9 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         }
     };
     do_pass(0, 0);
-    for (int base = NL * KPB, slot = 1; base < L; base += NL * KPB, slot ^= 1) {   // long panels only
+    // (requesting the next pass's K panel as soon as this pass's K registers are consumed -- under its softmax and PV -- measured
+    // slower: 34.2 vs 33.5 ms per generate at batch 64)
+    for (int base = NL * KPB, slot = 1; base < L; base += NL * KPB, slot ^= 1) {   // panels longer than one pass
         issue_k(base);
         do_pass(base, slot);
     }

@@ -743,7 +743,7 @@ struct Engine : EngineBase {
         } while (0)
 #define TXO_DA(MODE, APRO, NLV, WBV)                                                                          \
         do { if (narrow) TXO_DA1(MODE, APRO, NLV, WBV, true); else TXO_DA1(MODE, APRO, NLV, WBV, false); } while (0)
-        if (o.cross) TXO_DA(ATT_CROSS, APRO_LN2, 20, 1);
+        if (o.cross) TXO_DA(ATT_CROSS, APRO_LN2, DA_NL_CROSS, 1);
         else if (o.apro == APRO_NONE && o.path) {
             if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, true, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, false, true>), grid, blk, 0, s, a);
@@ -907,16 +907,18 @@ struct Engine : EngineBase {
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
     // Which decode path?  TXO_PERSIST=1 / 0 forces the persistent launch on / off (where it exists: decoder width 256 with 8
     // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
-    // 256 steps; profiles/r02_persist_ab.txt): bf16, 8..128 images (1711 vs 1472 images/s at batch 64, 2237 vs 2065 at 128).
+    // 256 steps; profiles/r02_persist_ab.txt, last table): bf16 for 1..128 and 192..256 images (1919 vs 1489 images/s at batch 64,
+    // 2429 vs 2029 at 128, 2615 vs 2575 at 256; 160 images -- 20 rows per team, a second row tile of 4 rows -- loses 4 %), fp32 for
+    // 48..128 images (997 vs 894 at 64).
     bool persist_usable(int B) const {
         if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
-        // measured A/B (profiles/r02_persist_ab.txt): the persistent launch wins for 8 <= B <= 128 in bf16 (one or two 16-row
-        // tiles per team); B <= 4 is the graph-replayed launch path's, B > 128 (3+ row tiles per team) and fp32 are a wash or lose
-        return sizeof(T) == 2 && D == 256 && B >= 8 && B <= 128;
+        if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
+        if (sizeof(T) == 2) return B <= 128 || (B >= 192 && B <= 256);
+        return B >= 48 && B <= 128;
     }
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {

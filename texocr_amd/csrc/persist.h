@@ -332,7 +332,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 s.K = a.ckv + (size_t)(2 * l) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.V = a.ckv + (size_t)(2 * l + 1) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.lmax = a.N; s.len = a.N;
-                PS_ATTN(ATT_CROSS, APRO_LN2, 20, s, pf_oc);
+                PS_ATTN(ATT_CROSS, APRO_LN2, DA_NL_CROSS, s, pf_oc);
             }
             {
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_c; g.bias = W.bo_c; g.A = lao; g.resid = lx; g.y_out = ly;
