@@ -1,6 +1,7 @@
 """Summarise the rocprofv3 --pmc passes of probes/collect_pmc.sh: average FETCH_SIZE / WRITE_SIZE (KB) per launch of every kernel and
 the corrected HBM bytes of the cross-attention launch (gfx950 reports half the bytes of 16-B/lane streaming reads in FETCH_SIZE:
 MI355X_MICROARCH.md, HBM section -> read bytes = 2 * FETCH_SIZE * 1024).  python probes/pmc_summary.py <dir> <dtype> [batch]"""
+import re
 import csv, glob, json, sys
 from collections import defaultdict
 
@@ -19,7 +20,7 @@ for name, c in sorted(acc.items()):
         continue
     e = {"FETCH_SIZE_KB_avg": round(sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"])), 1),
          "WRITE_SIZE_KB_avg": round(sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])), 1), "launches": len(c["FETCH_SIZE"])}
-    if "dec_attn_kernel" in name and ", 0, 1, 20," in name:          # cross attention (MODE 0, APRO_LN2, NL 20)
+    if "dec_attn_kernel" in name and re.search(r"dec_attn_kernel<[^,]+, 0, 1, \d+,", name):   # cross attention (MODE 0, APRO_LN2, any NL)
         e["algorithmic_bytes_per_launch"] = B * heads * 2 * N * 64 * esz
         e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
         cross = (name, e)
