@@ -226,4 +226,13 @@ __device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32
 __device__ inline u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 __device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
 
+// 16 bytes from an LDS BYTE ADDRESS (not a generic pointer: a ds_read_b128 for sure, never a flat load)
+__device__ inline float4 lds_ld_f4(unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *reinterpret_cast<const __attribute__((address_space(3))) float4*>((uintptr_t)addr);
+#else
+    (void)addr; return float4{};
+#endif
+}
+
 }  // namespace txo

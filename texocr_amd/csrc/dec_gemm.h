@@ -92,6 +92,7 @@ template <typename T> struct DecGemmArgs {
     const float* y;                 // PRO_LN2 / PRO_LNF: [rows][K] fp32 stream
     float* x_out;                   // PRO_EMBED / PRO_LN2: residual written here (block column 0 only)
     const float* gamma; const float* beta;
+    unsigned ln_lds;                // persistent kernel: LDS byte address of {gamma[K], beta[K]} copied there once, or 0 = read gamma / beta from memory
     const int64_t* tok; const float* tok_emb; const float* pos_emb;   // PRO_EMBED
     const int* t_ptr;               // decode position (device)
     int t_host;                     // >= 0: the position, known to the host (eager launches) -- saves the dependent scalar load; -1: read *t_ptr (graph replay)
@@ -237,8 +238,16 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
         const int sub = tid & 15, nv = FIXED ? NVMAX : K >> 6;
 #pragma unroll
         for (int i = 0; i < NVMAX; ++i) if (i < nv) {
-            lng[i] = *reinterpret_cast<const float4*>(a.gamma + i * 64 + sub * 4);
-            lnb[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
+            // every 16-lane row group needs the WHOLE gamma and beta: from memory that is 2 KB x 32 groups = 64 KB through the CU's
+            // one vector-memory pipeline per 512-thread stage -- 0.4 us in front of the poll, whose own reads return behind them.
+            // The persistent kernel keeps a copy in LDS (ds_read: another pipeline, another counter).
+            if (COH && a.ln_lds) {
+                lng[i] = lds_ld_f4(a.ln_lds + (i * 64 + sub * 4) * 4);
+                lnb[i] = lds_ld_f4(a.ln_lds + (K + i * 64 + sub * 4) * 4);
+            } else {
+                lng[i] = *reinterpret_cast<const float4*>(a.gamma + i * 64 + sub * 4);
+                lnb[i] = *reinterpret_cast<const float4*>(a.beta + i * 64 + sub * 4);
+            }
         }
     }
     // everything above is weights / biases; everything below reads what the previous stage produced

@@ -1014,6 +1014,8 @@ struct Engine : EngineBase {
                             (e[4] - t0) / 100.0);
                     if (e[5] && e[1])      // GEMM tile of the workgroup's first group: rows read + MFMAs | K reduction | epilogue
                         fprintf(f, " | tile: seen->mfma done %5.2f  reduce %5.2f  epilogue+stores %5.2f", (e[6] - e[1]) / 100.0, (e[7] - e[6]) / 100.0, (e[2] - e[7]) / 100.0);
+                    if (e[5] && e[0] && i > 0)   // before the poll: previous publication -> tile entry (stage set-up) -> poll begin (the tile's weight / bias / gamma requests)
+                        fprintf(f, " | pre: setup %5.2f  requests %5.2f", ((long long)e[5] - (long long)(e - PS_STAMP_WORDS)[4]) / 100.0, ((long long)e[0] - (long long)e[5]) / 100.0);
                     fprintf(f, "\n");
                 }
             }

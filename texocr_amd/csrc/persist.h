@@ -145,7 +145,8 @@ constexpr bool persist_w2_in_lds() {
 }
 template <typename T, int D_, int HEADS_>
 constexpr size_t persist_lds_bytes() {
-    return 2 * persist_group_lds<T, D_, HEADS_>() + 16 + (persist_w2_in_lds<T, D_>() ? 2 * (size_t)WBUF_REGS * 256 * 16 : 0);
+    return 2 * persist_group_lds<T, D_, HEADS_>() + 16 + (persist_w2_in_lds<T, D_>() ? 2 * (size_t)WBUF_REGS * 256 * 16 : 0) +
+           4 * (size_t)D_ * sizeof(float);                    // LayerNorm gamma / beta of the stack and of the final norm (dec_gemm.h: ln_lds)
 }
 
 template <typename T, int D_, int HEADS_>
@@ -189,7 +190,16 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, a.poll_sleep, nullptr};
     bool placement_checked = false;
 
+    // LayerNorm parameters -> LDS once: {gamma, beta} of the stack's shared norm, then of the final norm
+    float* ln_lds = reinterpret_cast<float*>(smem_all + 2 * GLDS + 16 + (persist_w2_in_lds<T, D_>() ? 2 * (size_t)WBUF_REGS * 256 * 16 : 0));
+    for (int c = threadIdx.x; c < D; c += PS_THREADS) {
+        ln_lds[c] = a.gamma[c]; ln_lds[D + c] = a.beta[c]; ln_lds[2 * D + c] = a.gamma_f[c]; ln_lds[3 * D + c] = a.beta_f[c];
+    }
+    __syncthreads();
+    const unsigned ln_lds_addr = (unsigned)(uintptr_t)ln_lds;     // low half of a generic LDS address = the LDS byte address
+
     DecGemmArgs<T> gb{};
+    gb.ln_lds = ln_lds_addr;
     gb.rows = nr; gb.gamma = a.gamma; gb.beta = a.beta; gb.t_ptr = nullptr; gb.D = D; gb.inner = ID; gb.heads = HEADS; gb.tmax = a.Tmax;
     float* lx = a.dx + (size_t)r0 * D; float* ly = a.dy + (size_t)r0 * D; float* lq = a.dq + (size_t)r0 * ID;
     T* lao = a.dao + (size_t)r0 * ID; T* lhid = a.dhid + (size_t)r0 * F; float* llog = a.dlogits + (size_t)r0 * a.V;
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         };
         {   // final LayerNorm + logits of this position (decoder.py:57-60)
             DecGemmArgs<T> g = gb; g.N = a.V; g.K = D; g.W = a.wlog; g.bias = a.blog; g.logits = llog; g.y = ly;
-            g.gamma = a.gamma_f; g.beta = a.beta_f;
+            g.gamma = a.gamma_f; g.beta = a.beta_f; g.ln_lds = ln_lds_addr + 2 * D * (unsigned)sizeof(float);
             PS_GEMM(PRO_LNF, EPI_LOGITS, KWP, 32, g, nc_log, PF_P, pf_step);
         }
         {   // greedy token, append, eos bookkeeping (decoder.py:103-116): one wave per row, rows dealt over the team's workgroups
