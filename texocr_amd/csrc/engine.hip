@@ -916,6 +916,7 @@ struct Engine : EngineBase {
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
+        if (persist_fallbacks >= 2) return false;              // it gave up twice on this device (not all 256 workgroups co-resident?): stop paying the time-out
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
         if (sizeof(T) == 2) return B <= 128 || (B >= 192 && B <= 256);
         return B >= 48 && B <= 128;
