@@ -454,6 +454,19 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     }
 }
 
+// A group WITHOUT a tile in a round of the persistent kernel: the workgroup barriers of dec_attn_tile (not BEAM) for a panel of
+// L keys and nothing else (see dec_gemm_idle)
+template <typename T, int MODE, int APRO, int NL, class Wait>
+__device__ __forceinline__ void dec_attn_idle(int L, Wait&& wait_prev) {
+    constexpr int KEYS_PER_PASS = NL * (64 / (DH / Elem<T>::PER16)) * 4;
+    wait_prev();
+    if constexpr (APRO != APRO_NONE) { __syncthreads(); __syncthreads(); }   // normalised row written; projection written
+    if constexpr (MODE == ATT_SELF && APRO != APRO_NONE) __syncthreads();   // k_t, v_t appended
+    __syncthreads();                                                        // first pass: wave maxima
+    for (int base = KEYS_PER_PASS; base < L; base += KEYS_PER_PASS) __syncthreads();
+    __syncthreads();                                                        // partial outputs
+}
+
 template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false>
 __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     __shared__ DecAttnLds<BEAM> lds;

@@ -377,6 +377,16 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
     }
 }
 
+// A group WITHOUT a tile in a round of the persistent kernel: the workgroup barriers of dec_gemm_tile_pf and nothing else (no
+// dummy tile on clamped addresses: its 16 KB of weight requests would sit in the CU's vector-memory pipeline in front of the
+// other group's)
+template <int PRO, class Wait>
+__device__ __forceinline__ void dec_gemm_idle(Wait&& wait_prev) {
+    wait_prev();
+    if constexpr (PRO != PRO_NONE) __syncthreads();           // A image written
+    __syncthreads();                                          // partial sums written
+}
+
 template <typename T, int PRO, int EPI, int KW, int BN, bool COH, class Wait>
 __device__ __forceinline__ void dec_gemm_tile(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem, bool valid,
                                               Wait&& wait_prev) {

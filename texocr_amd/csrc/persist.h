@@ -158,9 +158,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
     unsigned char* smem = smem_all + (size_t)grp * GLDS;
     int* lds_dead = reinterpret_cast<int*>(smem_all + 2 * GLDS);
-    const int sb = rank * 2 + grp;                            // this group among the team's 64 (GEMM tiles)
-    // attention tiles stream a K/V panel each (150 KB at 589 keys): they are dealt to the workgroups' FIRST groups before
-    // any second group gets one, so that a team with up to 32 tiles (batch 32) pulls them through 32 CUs instead of 16
+    // a stage's tiles are dealt to the workgroups' FIRST groups before any second group gets one: a stage of 32 tiles (the out
+    // projections, the logits; every attention stage up to batch 32) runs one tile on each of the team's 32 CUs instead of two on
+    // 16 -- half the weight / panel bytes through each CU's one vector-memory pipeline -- and a group without a tile only keeps
+    // the workgroup's barriers (dec_gemm_idle / dec_attn_idle)
     const int sa = grp * PS_TEAM_BLOCKS + rank;
     constexpr int NSB = PS_TEAM_BLOCKS * 2;
 
@@ -209,8 +210,8 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         ? a.stamps + ((size_t)team * PS_STAMP_RANKS + srank) * PS_MAX_STAGES * PS_STAMP_WORDS : nullptr;
 
     // the tile column this group takes in round 0 of a GEMM stage with `ncol` column tiles (what PS_GEMM computes)
-    auto bx0 = [&](int ncol) { const int nt = ncol * nrt; return (sb < nt ? sb : nt - 1) % ncol; };
-    auto has0 = [&](int ncol) { return rank * 2 < ncol * nrt; };        // this workgroup runs a tile in round 0
+    auto bx0 = [&](int ncol) { const int nt = ncol * nrt; return (sa < nt ? sa : nt - 1) % ncol; };
+    auto has0 = [&](int ncol) { return rank < ncol * nrt; };            // this workgroup runs a tile in round 0
     constexpr int KWP = ps_kw_pro<T>(D), KWI = ps_kw_half<T>(ID), KWF = ps_kw_half<T>(F);
     constexpr int NC_QKV = (3 * ID + 31) / 32, NC_O = 2 * D / 16, NC_F1 = 2 * F / 32, NC_F2 = D / 16;
     const int nc_log = (a.V + 31) / 32;
@@ -262,31 +263,34 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             const int ncol_ = (NCOL), nt_ = ncol_ * nrt;                                                                \
             for (int base_ = 0; base_ < nt_; base_ += NSB) {                                                            \
                 if (base_ > 0) __syncthreads();          /* the previous round's LDS reads are done */                  \
-                if (base_ + rank * 2 < nt_) {                                                                           \
-                    const int tile_ = base_ + sb; const bool ok_ = tile_ < nt_; const int tc_ = ok_ ? tile_ : nt_ - 1;  \
-                    if (base_ == 0) {                                                                                   \
+                if (base_ + rank < nt_) {                /* the workgroup's first group has a tile */                   \
+                    const int tile_ = base_ + sa;                                                                       \
+                    if (tile_ >= nt_) dec_gemm_idle<PRO>(ts);                                                           \
+                    else if (base_ == 0) {                                                                              \
                         auto args_ = ARGS;                                                                              \
-                        args_.stamps = (ts.stp && grp == 0) ? ts.stp + 5 - 3 * tc_ : nullptr;   /* tile stamps land at stp[5..7] */ \
-                        dec_gemm_tile_pf<T, PRO, EPI, KW, BN, true, PRE>(args_, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts, wbuf, PF); \
+                        args_.stamps = (ts.stp && grp == 0) ? ts.stp + 5 - 3 * tile_ : nullptr;   /* tile stamps land at stp[5..7] */ \
+                        dec_gemm_tile_pf<T, PRO, EPI, KW, BN, true, PRE>(args_, tile_ % ncol_, tile_ / ncol_, tid, smem, true, ts, wbuf, PF); \
                     }                                                                                                   \
-                    else dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tc_ % ncol_, tc_ / ncol_, tid, smem, ok_, ts);  \
+                    else dec_gemm_tile<T, PRO, EPI, KW, BN, true>(ARGS, tile_ % ncol_, tile_ / ncol_, tid, smem, true, ts); \
                 } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
             ts();                                                                                                       \
             ts.arrive();                                                                                                \
             ++stage;                                                                                                    \
         } while (0)
-#define PS_ATTN(MODE, APRO, NLV, ARGS, PF)                                                                              \
+        // LK: keys of the panel (a group without a tile mirrors the tile's barriers)
+#define PS_ATTN(MODE, APRO, NLV, ARGS, PF, LK)                                                                          \
         do {                                                                                                            \
             const int np_ = nr * HEADS;                                                                                 \
             for (int base_ = 0; base_ < np_; base_ += NSB) {                                                            \
                 if (base_ > 0) __syncthreads();                                                                         \
                 if (base_ + rank < np_) {                                                                               \
-                    const int p_ = base_ + sa; const bool ok_ = p_ < np_;                                               \
-                    if (base_ == 0) dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid, \
-                        *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts, PF);                           \
-                    else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, ok_ ? p_ : np_ - 1, tid,        \
-                        *reinterpret_cast<DecAttnLds<false>*>(smem), ok_, poll_wave, ts);                               \
+                    const int p_ = base_ + sa;                                                                          \
+                    if (p_ >= np_) dec_attn_idle<T, MODE, APRO, NLV>((LK), ts);                                         \
+                    else if (base_ == 0) dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, p_, tid,        \
+                        *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave, ts, PF);                          \
+                    else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, p_, tid,                        \
+                        *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave, ts);                              \
                 } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
             ts();                                                                                                       \
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             at.y = ly; at.x_out = lx; at.out = lao; at.qin = lq; at.tok = a.cur_tok + r0; at.tok_emb = a.tok_emb; at.pos_emb = a.pos_emb;
             {   // causal self attention over the cache (attention.py:148-173, one query)
                 DecAttnArgs<T> s = at; s.W = W.wqkv; s.K = kc; s.V = vc; s.lmax = a.Tmax; s.len = 0;
-                PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s, pf_os);
+                PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t + 1);
             }
             {   // gated output projection + residual (attention.py:96-99,180)
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_s; g.bias = W.bo_s; g.A = lao; g.resid = lx; g.y_out = ly;
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 s.K = a.ckv + (size_t)(2 * l) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.V = a.ckv + (size_t)(2 * l + 1) * a.cross_stride + (size_t)r0 * HEADS * a.N * DH;
                 s.lmax = a.N; s.len = a.N;
-                PS_ATTN(ATT_CROSS, APRO_LN2, DA_NL_CROSS, s, pf_oc);
+                PS_ATTN(ATT_CROSS, APRO_LN2, DA_NL_CROSS, s, pf_oc, a.N);
             }
             {
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_c; g.bias = W.bo_c; g.A = lao; g.resid = lx; g.y_out = ly;
