@@ -687,10 +687,11 @@ def _both_paths(m, img, max_len, **kw):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-@pytest.mark.parametrize("B", [1, 5, 64, 100])
+@pytest.mark.parametrize("B", [1, 5, 64, 100, 200])
 def test_persistent_decode_bit_identical_to_launches(dtype, B):
     """Same tile functions, same reduction orders: tokens AND per-step logits are bit-identical for every batch
-    size (1 row in one team ... 13 rows in each of 8 teams with a ragged last one)."""
+    size (1 row in one team ... 13 rows in each of 8 teams with a ragged last one ... 25 rows per team: two 16-row
+    tiles per GEMM stage and four rounds of attention pairs)."""
     d = Dims(canvas=224)
     d, sd, m = build(d, seed=3, dtype=dtype, max_batch=B)
     g = torch.Generator(device="cuda").manual_seed(77 + B)
