@@ -169,6 +169,12 @@ template <bool FAST> __device__ inline float rsqrt_sel(float x) {
     if constexpr (FAST) return __builtin_amdgcn_rsqf(x); else return 1.0f / sqrtf(x);
 }
 
+// exp(x): libm in the fp32 parity mode; perf mode (bf16 operands) takes v_exp_f32 on x * log2(e) (the decode attention evaluates one
+// per key slot on its critical path; exp(-huge) is still exactly 0, which the masking relies on)
+template <bool FAST> __device__ inline float exp_sel(float x) {
+    if constexpr (FAST) return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); else return expf(x);
+}
+
 // one LayerNorm element from its row statistics: the row kernels (rows.h) and the GEMM epilogues that rebuild the residual
 // x = LN(y) on the fly (gemm_big.h: EpiGluRes / EpiBiasRes with stats) share this form, so both give the same bits
 __device__ inline float ln_apply(float y, float mean, float rstd, float g, float b) { const float t = y - mean; return t * rstd * g + b; }

@@ -393,7 +393,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         __syncthreads();
         const float pm = fmaxf(fmaxf(stat[slot * 4 + 0], stat[slot * 4 + 1]), fmaxf(stat[slot * 4 + 2], stat[slot * 4 + 3]));
         const float m_new = fmaxf(m_run, pm);
-        const float alpha = expf(m_run - m_new);              // first pass: exp(-huge) = 0 with acc = l = 0
+        const float alpha = exp_sel<sizeof(T) == 2>(m_run - m_new);   // first pass: exp(-huge) = 0 with acc = l = 0
         m_run = m_new;
         l_run *= alpha;
 #pragma unroll
@@ -401,7 +401,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
             if (V_EARLY && u >= nslot) continue;
-            const float p = expf(sc[u] - m_new);              // masked keys: exp(-3e38 - m) == 0 exactly
+            const float p = exp_sel<sizeof(T) == 2>(sc[u] - m_new);   // masked keys: exp(-3e38 - m) == 0 exactly
             l_run = fmaf(p, count_me, l_run);
             float vf[PER16];
             if constexpr (HIST_EARLY) {
@@ -442,7 +442,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         float o = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         float l = (stat[8] + stat[9]) + (stat[10] + stat[11]);
         if constexpr (MODE == ATT_SELF && FUSED) {
-            const float p_new = expf(s_new - m_run);
+            const float p_new = exp_sel<sizeof(T) == 2>(s_new - m_run);
             o = fmaf(p_new, qkv[2][tid], o);
             l += p_new;
         }
