@@ -14,7 +14,9 @@
 // contiguous range of batch rows for the whole decode; rows of different teams never interact (the reference's only
 // cross-row operation is the GLOBAL eos test, decoder.py:115-116, handled below), so there is no chip-wide barrier
 // anywhere.  A workgroup is two 256-thread groups; a stage's tiles / (image, head) pairs are dealt over the team's 64
-// groups.
+// groups, first groups first (a stage of <= 32 tiles runs one per CU), and a group without a tile only keeps the
+// workgroup's barriers.  Resident in LDS for the whole launch: the FFN-out weight fragments of the workgroup's tile
+// (64 KB) and the LayerNorm parameters (4 KB).
 //
 // Hand-off (one per stage, all-to-all inside the team): every storing wave drains its stores (s_waitcnt vmcnt(0)),
 // workgroup barrier, ONE plain store of the stage number into the workgroup's word of the team's flag line; a consumer
