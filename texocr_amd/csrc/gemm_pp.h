@@ -41,7 +41,7 @@ __device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
 }
 
 #ifdef PP_STAMPS
-__device__ unsigned long long g_pp_dbg[4096];      // scratch/pp_bench.hip: block 0, waves 0 and 4: {loop start, loop end, epilogue end} per tile
+__device__ unsigned long long g_pp_dbg[4096];      // probes/pp_bench.hip: block 0, waves 0 and 4: {loop start, loop end, epilogue end} per tile
 #define PP_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0 && seq < 64) g_pp_dbg[(seq * 2 + wr) * 4 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define PP_STAMP(slot) do {} while (0)
