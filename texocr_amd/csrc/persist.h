@@ -230,12 +230,14 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
 
     // FFN-out (K = 4D: the longest weight rows of the step, 32 KB per tile) waited ~1.7 us per stage for its fragments to come
     // from the Infinity Cache (profiles/r02_persist_v6_stamps.txt: "reduce").  Its 16 tiles per layer are therefore pinned to
-    // 8 workgroups PER LAYER (ranks 8l .. 8l+7), which keep their tile's fragments in LDS for the whole decode: every thread
-    // parks its own 8 x 16 bytes there once and reads them back each position (thread-private: no synchronisation, same
-    // fragments -> same bits as the launch path).
+    // 16 workgroups PER LAYER, which keep their tile's fragments in LDS for the whole decode: every thread parks its own
+    // 8 x 16 bytes there once and reads them back each position (thread-private: no synchronisation, same fragments -> same
+    // bits as the launch path).
     constexpr bool W2_LDS_OK = persist_w2_in_lds<T, D_>();
     const bool w2_lds = W2_LDS_OK && a.Ld <= PS_TEAM_BLOCKS / 8;
-    const int w2_layer = rank >> 3, w2_tile = (rank & 7) * 2 + grp;              // this group's FFN-out tile column (of 16)
+    // group g of workgroup `rank` owns tile column (rank & 15) of layer (rank >> 4) + 2 g: a layer's 16 tiles run on 16 CUs, ONE
+    // per CU (two per CU on 8 CUs made each tile wait for the other's rows and fragments: "reduce" 0.7 us)
+    const int w2_layer = (rank >> 4) + 2 * grp, w2_tile = rank & 15;             // this group's layer and FFN-out tile column (of 16)
     unsigned char* w2_lds_base = smem_all + 2 * GLDS + 16 + (size_t)grp * (WBUF_REGS * 256 * 16);
     if constexpr (W2_LDS_OK) {
         if (w2_lds && w2_layer < a.Ld) {
@@ -363,19 +365,24 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 if constexpr (W2_LDS_OK) {
                     if (w2_lds) {                              // block-uniform
                         w2_done = true;
-                        if (w2_layer == l) {
+                        if ((rank >> 4) != (l & 1)) {              // this workgroup owns no tile of the layer
+                            ts(); pf_next();
+                        } else if (w2_layer != l) {                // the other group's layer: keep the barriers
+                            for (int by = 0; by < nrt; ++by) {
+                                if (by > 0) __syncthreads();
+                                dec_gemm_idle<PRO_NONE>(ts);
+                            }
+                        } else {
                             WBuf wb;
 #pragma unroll
                             for (int c = 0; c < KWF; ++c) wb.r[c] = ld16(w2_lds_base + ((size_t)c * 256 + tid) * 16);
                             for (int by = 0; by < nrt; ++by) {
                                 if (by > 0) __syncthreads();
                                 auto args_ = h;
-                                args_.stamps = (ts.stp && grp == 0 && by == 0) ? ts.stp + 5 - 3 * w2_tile : nullptr;
+                                args_.stamps = (ts.stp && by == 0) ? ts.stp + 5 - 3 * w2_tile : nullptr;
                                 if (by == 0) dec_gemm_tile_pf<T, PRO_NONE, EPI_BIAS_RES, KWF, 16, true, true>(args_, w2_tile, by, tid, smem, true, ts, wb, pf_next);
                                 else dec_gemm_tile_pf<T, PRO_NONE, EPI_BIAS_RES, KWF, 16, true, true>(args_, w2_tile, by, tid, smem, true, ts, wb, none);
                             }
-                        } else {
-                            ts(); pf_next();
                         }
                         ts();
                         ts.arrive();
