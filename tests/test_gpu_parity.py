@@ -702,6 +702,20 @@ def test_persistent_decode_bit_identical_to_launches(dtype, B):
     assert torch.equal(lp, ll)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_persistent_decode_bit_identical_to_launches_full_width(dtype):
+    """The same at the benchmark's image size (224 x 672: 589 keys, i.e. TWO passes of the cross attention in bf16 and
+    four in fp32) and a batch that leaves second groups without attention pairs (24 images: 3 rows per team)."""
+    d = Dims(canvas=672)
+    d, sd, m = build(d, seed=4, dtype=dtype, max_batch=24)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand((24, 3, 224, 672), generator=g, device="cuda")
+    (tp, lp), (tl, ll) = _both_paths(m, img, 12, return_logits=True)
+    assert tp.shape == (24, 12)
+    assert torch.equal(tp, tl)
+    assert torch.equal(lp, ll)
+
+
 def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
     """The persistent launch waits on other workgroups with bounded spins; when a hand-off times out (or a team turns out to
     span two XCDs) every workgroup leaves, the engine reports it and redoes the decode with launches.  A test hook makes
