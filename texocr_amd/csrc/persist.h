@@ -157,7 +157,8 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     constexpr size_t GLDS = persist_group_lds<T, D_, HEADS_>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     const int team = blockIdx.x % PS_TEAMS, rank = blockIdx.x / PS_TEAMS;
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), tid = threadIdx.x & 255;
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    int tid = threadIdx.x & 255;
     unsigned char* smem = smem_all + (size_t)grp * GLDS;
     int* lds_dead = reinterpret_cast<int*>(smem_all + 2 * GLDS);
     // a stage's tiles are dealt to the workgroups' FIRST groups before any second group gets one: a stage of 32 tiles (the out
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
 
     int t = 0;
     for (; t < a.max_len; ++t) {
+        // opaque per position: nothing derived from the thread index is hoisted out of the position loop (hipcc otherwise keeps
+        // dozens of per-thread addresses of all stages alive across the whole loop, in a kernel at the 256-VGPR limit)
+        asm volatile("" : "+v"(tid));
         gb.t_host = t;
         if (a.inject_fail > 0 && t == a.inject_fail && team == 0 && rank == 0) {   // TXO_PERSIST_INJECT_FAIL (tests): what a time-out does
             if (threadIdx.x == 0) { atomicOr(&ctl->fail, 1u); *lds_dead = 1; }
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             ++stage;                                                                                                    \
         } while (0)
         for (int l = 0; l < a.Ld; ++l) {
+            asm volatile("" : "+v"(tid));                     // ... nor out of the layer loop
             const PersistLayer<T>& W = a.L[l];
             T* kc = a.skv + (size_t)(2 * l) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
             T* vc = a.skv + (size_t)(2 * l + 1) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
