@@ -907,8 +907,8 @@ struct Engine : EngineBase {
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
     // Which decode path?  TXO_PERSIST=1 / 0 forces the persistent launch on / off (where it exists: decoder width 256 with 8
     // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
-    // 256 steps; profiles/r02_persist_ab.txt, last table): bf16 up to 256 images (24.3 vs 29.5 ms for ONE image, 1916 vs 1504
-    // images/s at batch 64, 2405 vs 2032 at 128, 2604 vs 2580 at 256; a tie at 160), fp32 for 16..128 images (1014 vs 901 at 64).
+    // 256 steps; profiles/r02_persist_ab.txt, last table): width 256, every batch size up to 256 images in both modes -- bf16
+    // 22.9 vs 29.1 ms for ONE image, 1998 vs 1522 images/s at batch 64, 2717 vs 2605 at 256; fp32 1094 vs 903 at batch 64.
     bool persist_usable(int B) const {
         if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
@@ -917,8 +917,7 @@ struct Engine : EngineBase {
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
         if (persist_fallbacks >= 2) return false;              // it gave up twice on this device (not all 256 workgroups co-resident?): stop paying the time-out
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
-        if (sizeof(T) == 2) return B <= 256;
-        return B >= 16 && B <= 128;
+        return B <= 256;                                       // more rows per team than two 16-row tiles: not measured
     }
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
