@@ -157,6 +157,7 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
     out = {"value": round(B / sec, 2), "unit": "images/sec", "ms_per_step": round(1000 * sec, 3), "batch": B, "dtype": dtype, "steps": steps}
     esz = 2 if dtype == "bf16" else 4
     eng = m._engine
+    out["decode_path"] = "one persistent launch (csrc/persist.h)" if eng.query(0) == 1 else "one launch per stage"
     if want_cross:
         eng.profile(2)
         m.generate(img, a.max_len)
@@ -165,7 +166,7 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
         eng.profile(0)
         algo = B * dims.dec_heads * 2 * N * 64 * esz
         ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention)", "bound": "hbm", "achieved": round(ach, 1),
+        out["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention; a separate generate() on the launch-per-stage path)", "bound": "hbm", "achieved": round(ach, 1),
                            "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "algorithmic_bytes_per_launch": algo,
                            "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n}
     if want_encoder:
