@@ -10,10 +10,15 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127
 FL="--steps 4 --warmup 1 --settle-seconds 0 --no-extras --no-cpu-baseline --no-roofline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b64 -- python3 bench.py $FL > $O/prof_r02_b64.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b256 -- python3 bench.py $FL --batch 256 > $O/prof_r02_b256.log 2>&1
+# the launch-per-stage path at batch 64 and 256 (the cross-attention kernel the `roofline_cross_attention_kernel` / `b256.roofline` objects time)
+export TXO_PERSIST=0
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b64_launches -- python3 bench.py $FL > $O/prof_r02_b64_launches.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_b256_launches -- python3 bench.py $FL --batch 256 > $O/prof_r02_b256_launches.log 2>&1
+unset TXO_PERSIST
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_cfg4 -- python3 bench.py $FL --batch 256 --model cfg4 --steps 2 > $O/prof_r02_cfg4.log 2>&1
 bash probes/collect_pmc.sh bf16 64
 bash probes/collect_pmc.sh bf16 256
 python3 probes/pmc_summary.py $O/pmc_bf16_b64 bf16 64 > $O/r02_pmc_bf16_b64.json
 python3 probes/pmc_summary.py $O/pmc_bf16_b256 bf16 256 > $O/r02_pmc_bf16_b256.json
-for d in b64 b256 cfg4; do f=$(find $O/prof_r02_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r02_${d}_bf16_kernel_stats.csv; done
+for d in b64 b256 cfg4 b64_launches b256_launches; do f=$(find $O/prof_r02_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r02_${d}_bf16_kernel_stats.csv; done
 ls -la $O | tail -20
