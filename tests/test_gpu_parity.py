@@ -102,6 +102,35 @@ def test_cfg2_shape_golden():
     np.testing.assert_allclose(logits[:, :8].cpu().numpy(), g["logits_first8"], atol=1e-4)
 
 
+@pytest.mark.parametrize("path", ["persistent", "launches"])
+def test_cfg2_benchmark_shape_golden_256_steps_inside_batch_64(path, monkeypatch):
+    """The benchmark's own shape pinned to the reference for the WHOLE decode: 3x224x672 (589 keys: two cross-attention passes
+    together with a self history beyond 128 positions), 256 greedy steps captured from the reference at B=2 -- decoded here as
+    rows 41 and 6 of a 64-image batch (rows never interact; decoder.py:115 is the only cross-row operation) on the fp32 engine,
+    through the persistent launch and through launches: every token exact (fixture margin >= 1e-4), logits within 1e-3."""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    assert float(g["margin"].min()) >= 1e-4 and g["tokens"].shape == (2, 256)
+    d, sd, m = build(meta, max_batch=64, max_tokens=589)
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand((64, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[41], img[6] = fix[0], fix[1]
+    enc = m.encoder(img[[41, 6]].contiguous())
+    np.testing.assert_allclose(enc[:, ::8].cpu().numpy(), g["enc_rows"], atol=5e-5)
+    monkeypatch.setenv("TXO_PERSIST", "1" if path == "persistent" else "0")
+    toks, logits = m.generate(img, 256, return_logits=True)
+    assert m._engine.query(0) == (1 if path == "persistent" else 0) and m._engine.query(1) == 0
+    assert toks.shape == (64, 256)
+    assert np.array_equal(toks[[41, 6]].cpu().numpy(), g["tokens"])
+    lg = logits[[41, 6]].cpu()
+    v = torch.gather(lg, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    err = float((v - torch.from_numpy(g["top5_vals"])).abs().max())
+    print(f"cfg2 t256 ({path}): max |dlogit| over the reference's top-5 of all 2x256 steps {err:.2e}")
+    assert err < 1e-3                                                                  # north_star bound
+    np.testing.assert_allclose(lg[:, :8].numpy(), g["logits_first8"], atol=1e-4)
+    np.testing.assert_allclose(lg[:, -4:].numpy(), g["logits_last4"], atol=1e-4)
+
+
 def test_position_ids_smaller_than_canvas():
     meta, g = load_golden("posids")
     lc = meta["live_case"]
@@ -716,6 +745,36 @@ def test_persistent_decode_bit_identical_to_launches_full_width(dtype):
     assert torch.equal(lp, ll)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B", [3, 64])
+def test_persistent_decode_samples_like_the_launch_path(dtype, B):
+    """The reference's DEFAULT decode samples (ocr_model.py:47, decoder.py:104-108).  decode='sample' runs inside the persistent
+    launch too: the sampler is the position's last stage, drawing from the same counter RNG keyed by (seed; row, position), so
+    the tokens AND the logits they were drawn from equal the launch path's bit for bit; another seed gives other tokens; with an
+    eos the GLOBAL break happens at the same position on both paths."""
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=3, dtype=dtype, max_batch=B)
+    g = torch.Generator(device="cuda").manual_seed(31 + B)
+    img = torch.rand((B, 3, 64, 224), generator=g, device="cuda")
+    kw = dict(temp=0.3, decode="sample", seed=11, return_logits=True)
+    (tp, lp), (tl, ll) = _both_paths(m, img, 40, **kw)
+    assert tp.shape == (B, 40) and torch.equal(tp, tl) and torch.equal(lp, ll)
+    greedy = m.generate(img, 40)
+    assert not torch.equal(tp, greedy), "sampling at temperature 0.3 never left the arg-max path"
+    (t2, _), _ = _both_paths(m, img, 40, temp=0.3, decode="sample", seed=12, return_logits=True)
+    assert not torch.equal(t2, tp)
+    # support: every drawn token is among the 99 largest logits of its step
+    top = lp.topk(99, dim=-1).indices
+    assert bool((top == tp[:, :, None]).any(-1).all())
+    # an eos that the sampled sequences hit: same early break on both paths
+    flat = tp.cpu().numpy()
+    cands = [tok for tok in range(d.vocab) if (flat == tok).any(axis=1).all()]
+    if cands:
+        m.eos_token = cands[0]
+        a, b = _both_paths(m, img, 40, temp=0.3, decode="sample", seed=11)
+        assert torch.equal(a, b) and a.shape[1] <= 40
+
+
 def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
     """The persistent launch waits on other workgroups with bounded spins; when a hand-off times out (or a team turns out to
     span two XCDs) every workgroup leaves, the engine reports it and redoes the decode with launches.  A test hook makes
@@ -792,6 +851,49 @@ def test_persistent_decode_global_eos_break():
     assert t2p.shape == (20, 1) and torch.equal(t2p, t2l)
 
 
+@pytest.mark.parametrize("stagger_us", ["150", "600"])
+def test_persistent_eos_break_when_teams_drift_apart(stagger_us, monkeypatch):
+    """Teams of the persistent launch are not synchronised with each other.  Started 150 / 600 us apart (TXO_PS_STAGGER_US: several
+    positions of drift between neighbouring teams, dozens between the first and the last) with a ragged batch, a team that has
+    seen the chip-wide done mask must still decode up to the position at which the LAST row of the batch first produced eos:
+    every returned column of every row equals the launch path's and the oracle's (no column left as allocated)."""
+    cpu_ref = _oracle()
+    d = Dims(canvas=224, vocab=16, bos=14, eos=5, pad=15, max_len=256)
+    d, sd, m = build(d, seed=11, max_batch=20)
+    img = torch.from_numpy(synth.synth_images(20, 3, 32, 96, seed=5)).cuda()
+    m.eos_token = None
+    monkeypatch.setenv("TXO_PERSIST", "0")
+    free = m.generate(img, 256).cpu().numpy()
+    # eos candidates: every row emits the token; take those whose LAST first-occurrence is in the first team (rows 0..2) or in the
+    # last one (rows 18..19) -- with the stagger the last team is the furthest behind, the first the furthest ahead
+    cands = []
+    for tok in range(d.vocab):
+        hit = free == tok
+        if hit.any(axis=1).all():
+            first = hit.argmax(axis=1)
+            if first.max() > first.min() + 2 and first.max() < 200:
+                cands.append((tok, int(first.max()), int(first.argmax())))
+    assert cands
+    for eos, last, row in cands[:4]:
+        m.eos_token = eos
+        monkeypatch.setenv("TXO_PERSIST", "0")
+        tl = m.generate(img, 256)
+        monkeypatch.setenv("TXO_PERSIST", "1"); monkeypatch.setenv("TXO_PS_STAGGER_US", stagger_us)
+        for _ in range(3):
+            fill = torch.full((20, 256), -7, dtype=torch.int64, device="cuda")      # poison: an undecoded column would show
+            del fill
+            tp = m.generate(img, 256)
+            assert m._engine.query(0) == 1 and m._engine.query(1) == 0
+            assert tp.shape == (20, last + 1), (eos, last, row, tuple(tp.shape))
+            assert torch.equal(tp, tl), (eos, last, row)
+        monkeypatch.delenv("TXO_PS_STAGGER_US")
+        assert np.array_equal(tp.cpu().numpy(), free[:, :last + 1])
+    ref = cpu_ref.generate_cached(cpu_ref.to_torch_sd(sd), img.cpu(), d.bos, cands[0][0], 256)
+    m.eos_token = cands[0][0]
+    monkeypatch.setenv("TXO_PERSIST", "1"); monkeypatch.setenv("TXO_PS_STAGGER_US", stagger_us)
+    assert np.array_equal(m.generate(img, 256).cpu().numpy(), ref.numpy())
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE configs 2 (bf16), 4 and 5 at their full sizes
 # ------------------------------------------------------------------------------------------------
@@ -848,6 +950,30 @@ def test_cfg4_full_size_b256():
     assert torch.equal(mb.generate(img, 256), t1)
     perm = torch.randperm(256, device="cuda", generator=gen)
     assert torch.equal(mb.generate(img[perm].contiguous(), 256), t1[perm])
+
+
+def test_cfg4_golden_64_steps_inside_batch_256():
+    """ViT-Base + 6L decoder pinned to the reference beyond the first positions: 64 greedy steps at B=2 from the reference, decoded
+    as rows 200 and 33 of a 256-image batch on the fp32 engine (tokens exact, logits within 1e-3)."""
+    meta, g = load_golden("cfg4_b2_224x672_t64")
+    assert float(g["margin"].min()) >= 1e-4 and g["tokens"].shape == (2, 64)
+    d = Dims(**meta["dims"])
+    sd = synth.synth_state_dict(d, meta["weight_seed"])
+    from texocr_amd.model import model_from_dims
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    img = torch.rand((256, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[200], img[33] = fix[0], fix[1]
+    m = model_from_dims(d, dtype="fp32", max_batch=256, max_tokens=589)
+    m.load_state_dict(sd)
+    toks, logits = m.generate(img, 64, return_logits=True)
+    assert np.array_equal(toks[[200, 33]].cpu().numpy(), g["tokens"])
+    lg = logits[[200, 33]].cpu()
+    v = torch.gather(lg, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    err = float((v - torch.from_numpy(g["top5_vals"])).abs().max())
+    print(f"cfg4 t64: max |dlogit| over the reference's top-5 of all 2x64 steps {err:.2e}")
+    assert err < 1e-3
+    np.testing.assert_allclose(lg[:, -4:].numpy(), g["logits_last4"], atol=2e-4)
 
 
 def test_cfg5_full_size_beam5_bucketed():

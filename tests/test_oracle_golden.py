@@ -178,6 +178,32 @@ def test_cfg4_vit_base_encoder_and_decode():
     np.testing.assert_allclose(logits.numpy(), g["step_logits"], atol=5e-5)
 
 
+def test_cfg2_benchmark_shape_256_steps():
+    """The benchmark's own shape for the whole decode: 3x224x672, B=2, 256 reference steps (min margin >= 1e-4)."""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    d, sd, img = model_of(meta)
+    assert float(g["margin"].min()) >= 1e-4 and meta["max_len"] == 256
+    enc = cpu_ref.encode(sd, img)
+    np.testing.assert_allclose(enc[:, ::8].numpy(), g["enc_rows"], atol=2e-5)
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, 256, collect_logits=True, enc=enc)
+    assert np.array_equal(toks.numpy(), g["tokens"]), first_divergence(toks.numpy(), g["tokens"])
+    v = torch.gather(logits, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    np.testing.assert_allclose(v.numpy(), g["top5_vals"], atol=5e-5)
+    np.testing.assert_allclose(logits[:, -4:].numpy(), g["logits_last4"], atol=5e-5)
+
+
+def test_cfg4_vit_base_64_steps():
+    """BASELINE config 4 for 64 reference steps (B=2)."""
+    meta, g = load_golden("cfg4_b2_224x672_t64")
+    d, sd, img = model_of(meta)
+    assert float(g["margin"].min()) >= 1e-4
+    toks, logits = cpu_ref.generate_cached(sd, img, d.bos, d.eos, 64, collect_logits=True)
+    assert np.array_equal(toks.numpy(), g["tokens"]), first_divergence(toks.numpy(), g["tokens"])
+    v = torch.gather(logits, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    np.testing.assert_allclose(v.numpy(), g["top5_vals"], atol=1e-4)
+    np.testing.assert_allclose(logits[:, -4:].numpy(), g["logits_last4"], atol=1e-4)
+
+
 def test_wrapper_fixture_preprocess_and_decode():
     """N3: the oracle on the tensor the reference's wrapper fed its model (hybrid default factory), inside the
     positional table and beyond it (the reference slides its window, decoder.py:99-100: recompute mode only);

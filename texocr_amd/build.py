@@ -14,17 +14,41 @@ SOURCES = ["engine.hip"]
 HEADERS = ["common.h", "conv.h", "gemm_big.h", "gemm_pp.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "step.h", "persist.h"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(OUT):
+# Mandatory flags (never replaced by the environment):
+# -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs (see below); -ffp-contract=on: the bit-identity of the two decode
+# paths depends on it (see below).  TXO_HIPCC_FLAGS only ADDS flags (e.g. -DTXO_XS_VE=4 for an experiment build).
+BASE_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result",
+              "-mllvm", "-amdgpu-mfma-vgpr-form", "-ffp-contract=on"]
+
+
+def _flags() -> list:
+    return BASE_FLAGS + os.environ.get("TXO_HIPCC_FLAGS", "").split()
+
+
+def _stamp(out: str) -> str:
+    return out + ".flags"
+
+
+def _stale(out: str) -> bool:
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    # a library built with other flags is stale whatever its age (the flags of the last build are kept beside it; a library
+    # that travelled to the GPU box keeps its stamp, so it is not rebuilt there)
+    try:
+        with open(_stamp(out)) as f:
+            if f.read().split() != _flags():
+                return True
+    except OSError:
+        return True
+    t = os.path.getmtime(out)
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "texocr.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
-        return OUT
+def build(force: bool = False, verbose: bool = True, out: str = "") -> str:
+    out = out or os.environ.get("TXO_LIB_OUT", "") or OUT
+    if not force and not _stale(out):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -amdgpu-mfma-vgpr-form: MFMA accumulators in ordinary VGPRs.  Every kernel here fits 256 registers, and the attention
     # kernels read their score tiles with the VALU right after the MFMA: with accumulators in AGPRs the compiler copied ~250
@@ -32,13 +56,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # -ffp-contract=on: a*b+c fuses only INSIDE one source expression (hipcc's default, "fast", lets the backend fuse across
     # statements, and it decides per surrounding code: the same inlined tile function then rounds differently in the
     # per-stage kernels and in the persistent decode kernel, which are required to give the same bits).
-    extra = os.environ.get("TXO_HIPCC_FLAGS", "-mllvm -amdgpu-mfma-vgpr-form -ffp-contract=on").split()
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-Wno-unused-result", *extra,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", OUT]
+    cmd = [hipcc, *_flags(), *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     if verbose:
         print("[texocr_amd.build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return OUT
+    with open(_stamp(out), "w") as f:
+        f.write(" ".join(_flags()) + "\n")
+    return out
 
 
 def build_example(verbose: bool = True) -> str:
@@ -59,4 +83,5 @@ def build_example(verbose: bool = True) -> str:
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
-    build_example()
+    if "--example" in sys.argv:            # needs gcc and the HIP headers; __graft_entry__.build() builds it too
+        build_example()

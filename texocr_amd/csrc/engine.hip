@@ -910,7 +910,9 @@ struct Engine : EngineBase {
     // 256 steps; profiles/r02_persist_ab.txt, last table): width 256, every batch size up to 256 images in both modes -- bf16
     // 22.9 vs 29.1 ms for ONE image, 1998 vs 1522 images/s at batch 64, 2717 vs 2605 at 256; fp32 1094 vs 903 at batch 64.
     bool persist_usable(int B) const {
-        if (sample_mode || prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
+        // sampling: the persistent kernel keeps one row per wave in the LDS of the GEMM tiles (8 waves x V floats)
+        if (sample_mode && (size_t)V * sizeof(float) * (PS_THREADS / 64) > 2 * ((size_t)DG_BM * D * sizeof(T) + 8192)) return false;
+        if (prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
@@ -923,8 +925,11 @@ struct Engine : EngineBase {
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
         const size_t lds = persist_lds_bytes<T, D_, H_>();
         auto kern = decode_persist_kernel<T, D_, H_>;
-        static bool attr_set = false;
-        if (!attr_set) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+        // per DEVICE, not per process (one process may drive several GPUs through several engines): set on every launch, it is cheap
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TXO_E_STATE, "persistent decode: the device refused the launch's dynamic LDS size");   // -> decode with launches
+        }
         if (prof_persist && pool.used + 2 <= pool.ev.size()) {      // events bound to the dispatch itself (its begin / end timestamps)
             hipEvent_t e0 = pool.next(), e1 = pool.next();
             hipExtLaunchKernelGGL(kern, dim3(PS_TEAMS * PS_TEAM_BLOCKS), dim3(PS_THREADS), lds, s, e0, e1, 0, pa);
@@ -950,19 +955,23 @@ struct Engine : EngineBase {
         pa.cur_tok = cur_tok; pa.eos_seen = eos_seen; pa.skv = skv; pa.ckv = ckv;
         pa.self_stride = (size_t)sB * Id * Tmax; pa.cross_stride = (size_t)sImg * N * Id;
         pa.tokens_out = tokens_out; pa.out_stride = max_len; pa.logits_out = logits_out;
+        pa.sample = sample_mode; pa.sample_topk = sample_topk; pa.inv_temp = 1.0f / sample_temp; pa.seed = sample_seed;
         pa.ctl = pctl; pa.stamps = pstamps;
         const char* stamp_file = getenv("TXO_PSTAMPS");
         pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
         if (const char* sg = getenv("TXO_PS_STAGGER_US")) pa.stagger_ticks = (int)(atof(sg) * 100.0);
         pa.poll_sleep = 1;
         if (const char* ps = getenv("TXO_PS_POLL_SLEEP")) pa.poll_sleep = atoi(ps);
+        if (const char* em = getenv("TXO_PS_EARLY")) pa.early_mask = atoi(em);
+        pa.poll_mode = 0;                                         // scalar-load polls (persist.h: TeamSync::poll)
+        if (const char* pm = getenv("TXO_PS_POLL")) pa.poll_mode = atoi(pm);
         if (const char* inj = getenv("TXO_PERSIST_INJECT_FAIL")) pa.inject_fail = atoi(inj);   // tests: the give-up / fall-back path
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
         if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));
         if (D == 256) { if (int r = launch_persist<256, 8>(pa, s)) return r; }
         else if constexpr (sizeof(T) == 2) { if (int r = launch_persist<768, 12>(pa, s)) return r; }
         else return TXO_E_STATE;
-        HIP_TRY(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) return fail(TXO_E_STATE, "persistent decode: the launch was refused");   // -> decode with launches
         HIP_TRY(hipMemcpyAsync(pctl_host, pctl, sizeof(PersistCtl), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         const PersistCtl& c = *pctl_host;
@@ -979,6 +988,10 @@ struct Engine : EngineBase {
             }
             if (all) steps = std::min(max_len, last + 1);
         }
+        // every team must have decoded every position that is returned (teams are not synchronised with each other; the kernel
+        // lets a team stop only at or beyond the batch's last first-eos position -- checked here, never assumed)
+        for (int k = 0; k < nteams; ++k)
+            if (c.steps_run[k] < steps) { g_err = "persistent decode: a team stopped before the batch's last position"; return TXO_E_STATE; }
         if (stamp_file) dump_persist_stamps(stamp_file, nteams);
         *n_steps = steps;
         return 0;
@@ -1011,8 +1024,12 @@ struct Engine : EngineBase {
                     fprintf(f, "  L%-2d %-30s poll %5.2f  work %5.2f  drain %5.2f  pub %5.2f | end %7.2f", i < 7 * cfg.dec_layers ? i / 7 : -1, nm,
                             e[0] ? (e[1] - e[0]) / 100.0 : 0.0, e[1] ? (e[2] - e[1]) / 100.0 : 0.0, (e[3] - e[2]) / 100.0, (e[4] - e[3]) / 100.0,
                             (e[4] - t0) / 100.0);
-                    if (e[5] && e[1])      // GEMM tile of the workgroup's first group: rows read + MFMAs | K reduction | epilogue
+                    const bool attn = i < 7 * cfg.dec_layers && (i % 7 == 1 || i % 7 == 3);
+                    if (e[5] && e[1] && !attn)   // GEMM tile of the workgroup's first group: rows read + MFMAs | K reduction | epilogue
                         fprintf(f, " | tile: seen->mfma done %5.2f  reduce %5.2f  epilogue+stores %5.2f", (e[6] - e[1]) / 100.0, (e[7] - e[6]) / 100.0, (e[2] - e[7]) / 100.0);
+                    if (e[5] && e[1] && attn)    // attention tile of the workgroup's first group: wait end -> last pass's scores and PV done | reductions + store
+                        fprintf(f, " | tile: seen->panel consumed %5.2f  reduce+store %5.2f  (other group / barrier %5.2f)", ((long long)e[6] - (long long)e[1]) / 100.0,
+                                (e[7] - e[6]) / 100.0, ((long long)e[2] - (long long)e[7]) / 100.0);
                     if (e[5] && e[0] && i > 0)   // before the poll: previous publication -> tile entry (stage set-up) -> poll begin (the tile's weight / bias / gamma requests)
                         fprintf(f, " | pre: setup %5.2f  requests %5.2f", ((long long)e[5] - (long long)(e - PS_STAMP_WORDS)[4]) / 100.0, ((long long)e[0] - (long long)e[5]) / 100.0);
                     fprintf(f, "\n");

@@ -263,17 +263,21 @@ template <class Epi>
 inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi) {
     const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
     const int n_tiles = tiles_m * tiles_n;
-    static int cus = 0;                               // persistent grid: one block per CU (160 KiB of LDS each)
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    // persistent grid: one block per CU (160 KiB of LDS each).  Both the CU count and the > 64 KiB dynamic-LDS opt-in are per
+    // DEVICE (one process may drive several GPUs through several engines), so they are kept per device ordinal
+    static int cus_of[64] = {0}; static bool attr_of[64] = {false};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const int di = (dev >= 0 && dev < 64) ? dev : 0;
+    if (!cus_of[di] || di != dev) {
+        hipDeviceProp_t prop;
+        cus_of[di] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
-    static bool attr_set = false;                     // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
+    const int cus = cus_of[di];
+    if (!attr_of[di] || di != dev) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pp_kernel<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   PP_SMEM_BYTES);
-        attr_set = true;
+        attr_of[di] = true;
     }
     // band width: all column tiles when W is small enough to stay in an XCD's L2 anyway (or K is long: A panels are then
     // the larger operand and must not be re-streamed per band), else as many column tiles as ~1.6 MB of W

@@ -35,8 +35,18 @@
 #include "dec_gemm.h"
 #include "step.h"
 
+// build-time experiment switches (probes/ab_libs.sh): weights requested one stage ahead into registers
+#ifndef TXO_PS_AHEAD
+#define TXO_PS_AHEAD false
+#endif
+// per-tile stamps of the attention stages in the TXO_PSTAMPS dump (diagnostic build: -DTXO_PS_ATTN_STAMPS=true)
+#ifndef TXO_PS_ATTN_STAMPS
+#define TXO_PS_ATTN_STAMPS false
+#endif
+
 namespace txo {
 
+constexpr bool PS_ATTN_STAMPS = TXO_PS_ATTN_STAMPS;
 constexpr int PS_TEAMS = 8, PS_TEAM_BLOCKS = 32, PS_THREADS = 512, PS_MAXLD = 8;
 constexpr int PS_MAX_STAGES = 7 * PS_MAXLD + 2, PS_STAMP_RANKS = 4, PS_STAMP_WORDS = 8;   // 5 hand-off ticks + the tile's {entry, operands consumed, reduced}
 
@@ -70,6 +80,9 @@ template <typename T> struct PersistArgs {
     int64_t* tokens_out; int out_stride; float* logits_out;
     PersistCtl* ctl;
     int poll_sleep;                                           // TeamSync: 64-clock sleeps between two polls of the flag line
+    int sample; int sample_topk; float inv_temp; unsigned long long seed;   // sample != 0: the reference's sampler ends a position (step.h: sample_row) instead of the arg-max
+    int early_mask;                                           // bit 0 / 1: the POLLING wave also requests its self-attention history / its cross K panel before the wait (its poll then returns behind them)
+    int poll_mode;                                            // TeamSync::poll (0 vector sc1 loads, 1 scalar glc loads, 2 scalar loads behind s_dcache_inv)
     int inject_fail;                                          // test hook: position at which team 0 reports a hand-off time-out (0 = never)
     int stagger_ticks;                                        // experiment: team k starts k * this many 10-ns ticks late (desynchronises the teams' HBM phases)
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
@@ -81,12 +94,24 @@ template <typename T> struct PersistArgs {
 // poll (lane r reads workgroup r's word) until every word has reached the stage it waits for.  No atomic is involved: an
 // agent-scope atomic add executes at the memory side, ~0.5-1 us away, and cost more than the stage's arithmetic
 // (profiles/r02_persist_v4_stamps.txt: "pub").
+typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+__device__ inline unsigned min8(const u32x8& v) {
+    return min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(v[4], v[5]), min(v[6], v[7])));
+}
+constexpr unsigned PS_GIVE_UP_TICKS = 400000u;                // bounded spins: 4 ms of the 100 MHz counter (a hand-off takes 1-10 us)
+
 struct TeamSync {
     unsigned* flags;                                          // this team's line: PS_TEAM_BLOCKS words
     int rank; unsigned epoch;                                 // stages this workgroup has finished
     unsigned* fail; int* lds_dead; bool armed, dead;
     int poll_sleep;                                           // s_sleep(1) units (64 clocks) between two polls
+    // poll: 0 = one vector load of the line per poll (sc1: served by the XCD's L2); 1 = SCALAR loads with glc (forced miss in the
+    // scalar cache: also the L2's copy); 2 = scalar loads behind s_dcache_inv.  The scalar path keeps the poll out of the wave's
+    // vector-memory queue: vector loads return in order, so a wave that polls with vector loads cannot request its K/V panel or
+    // weights BEFORE the wait without the poll's data arriving behind them -- with scalar polls EVERY wave requests early.
+    int poll;
     unsigned long long* stp;                                  // diagnostic: 5 ticks per stage (wait begin / end, drain begin / end, published)
+    __device__ inline bool early_all() const { return poll != 0; }
     __device__ inline void operator()() {                     // wait until every workgroup of the team has finished the previous stage
         if (!armed) return;
         armed = false;
@@ -94,20 +119,56 @@ struct TeamSync {
             if (stp && threadIdx.x == 0) stp[0] = __builtin_amdgcn_s_memrealtime();
             const int lane = threadIdx.x;
             unsigned spins = 0;
-            // ONE poll in flight.  (Four, a quarter of a round trip apart, to see the last arrival sooner: 37.2 vs 36.5 ms per
-            // generate -- the extra reads of the line queue in front of the arrivals' stores at its L2 channel.)
-            for (;;) {
-                const unsigned v = lane < PS_TEAM_BLOCKS ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
-                if (__builtin_amdgcn_ballot_w64(v < epoch) == 0ull) break;
-                for (int i = 0; i < poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0u) {                // ~ every 0.3 ms: give up after ~80 ms or when another workgroup has
-                    if (spins > (1u << 18) || __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+            if (poll != 0) {
+                // the whole 128-byte line + the launch's fail word per poll, through the scalar data path (lgkmcnt, not vmcnt)
+                for (;;) {
+                    u32x8 f0, f1, f2, f3; unsigned fl;
+                    if (poll == 3) {                          // invalidate the scalar cache, then ordinary scalar loads (they miss it and read the L2)
+                        asm volatile("s_dcache_inv\n\t"
+                                     "s_load_dwordx8 %0, %5, 0x0\n\t"
+                                     "s_load_dwordx8 %1, %5, 0x20\n\t"
+                                     "s_load_dwordx8 %2, %5, 0x40\n\t"
+                                     "s_load_dwordx8 %3, %5, 0x60\n\t"
+                                     "s_load_dword %4, %6, 0x0\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&s"(f0), "=&s"(f1), "=&s"(f2), "=&s"(f3), "=&s"(fl) : "s"(flags), "s"(fail) : "memory");
+                    } else {
+                    if (poll == 2) asm volatile("s_dcache_inv" ::: "memory");
+                    asm volatile("s_load_dwordx8 %0, %5, 0x0 glc\n\t"
+                                 "s_load_dwordx8 %1, %5, 0x20 glc\n\t"
+                                 "s_load_dwordx8 %2, %5, 0x40 glc\n\t"
+                                 "s_load_dwordx8 %3, %5, 0x60 glc\n\t"
+                                 "s_load_dword %4, %6, 0x0 glc\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&s"(f0), "=&s"(f1), "=&s"(f2), "=&s"(f3), "=&s"(fl) : "s"(flags), "s"(fail) : "memory");
+                    }
+                    const unsigned behind = min(min(min8(f0), min8(f1)), min(min8(f2), min8(f3)));
+                    if (behind >= epoch) break;
+                    // give up when another workgroup has (every hand-off sees the fail word) or after PS_GIVE_UP_TICKS
+                    if (fl != 0u || ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t_begin > PS_GIVE_UP_TICKS)) {
                         if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
                         break;
                     }
+                    for (int i = 0; i < poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
                 }
+            } else {
+                // ONE poll in flight.  (Four, a quarter of a round trip apart, to see the last arrival sooner: 37.2 vs 36.5 ms per
+                // generate -- the extra reads of the line queue in front of the arrivals' stores at its L2 channel.)
+                for (;;) {
+                    const unsigned v = lane < PS_TEAM_BLOCKS ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+                    if (__builtin_amdgcn_ballot_w64(v < epoch) == 0ull) break;
+                    for (int i = 0; i < poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255u) == 0u) {             // give up after PS_GIVE_UP_TICKS or when another workgroup has
+                        if (__builtin_amdgcn_s_memrealtime() - t_begin > PS_GIVE_UP_TICKS ||
+                            __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
+                            break;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (stp && threadIdx.x == 0) stp[1] = __builtin_amdgcn_s_memrealtime();
         }
         __syncthreads();
@@ -191,7 +252,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         while (__builtin_amdgcn_s_memrealtime() - t0 < until) __builtin_amdgcn_s_sleep(8);
     }
     __syncthreads();
-    TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, a.poll_sleep, nullptr};
+    TeamSync ts{&ctl->flags[team][0], rank, 0u, &ctl->fail, lds_dead, false, false, a.poll_sleep, a.poll_mode, nullptr};
     bool placement_checked = false;
 
     // LayerNorm parameters -> LDS once: {gamma, beta} of the stack's shared norm, then of the final norm
@@ -207,7 +268,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     gb.rows = nr; gb.gamma = a.gamma; gb.beta = a.beta; gb.t_ptr = nullptr; gb.D = D; gb.inner = ID; gb.heads = HEADS; gb.tmax = a.Tmax;
     float* lx = a.dx + (size_t)r0 * D; float* ly = a.dy + (size_t)r0 * D; float* lq = a.dq + (size_t)r0 * ID;
     T* lao = a.dao + (size_t)r0 * ID; T* lhid = a.dhid + (size_t)r0 * F; float* llog = a.dlogits + (size_t)r0 * a.V;
-    const bool poll_wave = threadIdx.x < 64;
+    const bool poll_wave = threadIdx.x < 64 && !ts.early_all();   // a wave that polls with VECTOR loads requests its panel behind the wait
     const int srank = rank == 0 ? 0 : (rank == 10 ? 1 : (rank == 20 ? 2 : (rank == PS_TEAM_BLOCKS - 1 ? 3 : -1)));
     unsigned long long* stamp_base = (a.stamps && srank >= 0 && threadIdx.x == 0)
         ? a.stamps + ((size_t)team * PS_STAMP_RANKS + srank) * PS_MAX_STAGES * PS_STAMP_WORDS : nullptr;
@@ -223,7 +284,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     // PS_AHEAD: request a stage's weights one stage ahead into `wbuf`.  Measured (profiles/r02_persist_*): the 32 extra live
     // registers push the attention stages (already at the 256-VGPR limit of an 8-wave workgroup) into scratch, and the
     // arrival's vmcnt(0) drain waits for the early request anyway (vector memory returns in order) -- slower, so off.
-    constexpr bool PS_AHEAD = false;
+    constexpr bool PS_AHEAD = TXO_PS_AHEAD;
     constexpr bool PF_P = PS_AHEAD && KWP > 0 && wfrag_regs(KWP, 32) <= WBUF_REGS, PF_I = PS_AHEAD && KWI > 0 && wfrag_regs(KWI, 16) <= WBUF_REGS,
                    PF_F = PS_AHEAD && KWF > 0 && wfrag_regs(KWF, 16) <= WBUF_REGS;
     WBuf wbuf;
@@ -287,6 +348,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             ++stage;                                                                                                    \
         } while (0)
         // LK: keys of the panel (a group without a tile mirrors the tile's barriers)
+#ifndef TXO_PS_WBS
+#define TXO_PS_WBS 3
+#endif
+#define PS_WB(MODE, APRO) ((MODE) == ATT_SELF && (APRO) != APRO_NONE && sizeof(T) == 2 ? TXO_PS_WBS : 1)   /* as the launch path: engine.hip WBS */
 #define PS_ATTN(MODE, APRO, NLV, ARGS, PF, LK)                                                                          \
         do {                                                                                                            \
             const int np_ = nr * HEADS;                                                                                 \
@@ -295,10 +360,14 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 if (base_ + rank < np_) {                                                                               \
                     const int p_ = base_ + sa;                                                                          \
                     if (p_ >= np_) dec_attn_idle<T, MODE, APRO, NLV>((LK), ts);                                         \
-                    else if (base_ == 0) dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, p_, tid,        \
-                        *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave, ts, PF);                          \
-                    else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, p_, tid,                        \
-                        *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave, ts);                              \
+                    else if (base_ == 0) {                                                                              \
+                        auto args_ = ARGS;                                                                              \
+                        args_.stamps = (PS_ATTN_STAMPS && ts.stp && grp == 0) ? ts.stp + 5 - 3 * p_ : nullptr;   /* tile stamps land at stp[5..7] */ \
+                        dec_attn_tile<T, MODE, APRO, NLV, PS_WB(MODE, APRO), false, false, true>(args_, p_, tid,                       \
+                            *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave && !((a.early_mask >> (MODE == ATT_SELF ? 0 : 1)) & 1), ts, PF); \
+                    }                                                                                                   \
+                    else dec_attn_tile<T, MODE, APRO, NLV, PS_WB(MODE, APRO), false, false, true>(ARGS, p_, tid,          \
+                        *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave && !((a.early_mask >> (MODE == ATT_SELF ? 0 : 1)) & 1), ts); \
                 } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
             ts();                                                                                                       \
@@ -324,8 +393,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             {   // LN sandwich (or token + position embedding) + q,k,v projection; k,v appended to the cache (attention.py:124-127)
                 DecGemmArgs<T> g = gb; g.N = 3 * ID; g.K = D; g.W = W.wqkv; g.y = ly; g.x_out = lx;
                 g.tok = a.cur_tok + r0; g.tok_emb = a.tok_emb; g.pos_emb = a.pos_emb; g.q_out = lq; g.k_cache = kc; g.v_cache = vc;
+#ifndef TXO_PS_FUSED_SELF
                 if (l == 0) PS_GEMM(PRO_EMBED, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
                 else PS_GEMM(PRO_LN2, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
+#endif
             }
             if (!placement_checked) {                         // every workgroup of the team has ORed its XCC id in by now
                 placement_checked = true;
@@ -343,7 +414,13 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             at.y = ly; at.x_out = lx; at.out = lao; at.qin = lq; at.tok = a.cur_tok + r0; at.tok_emb = a.tok_emb; at.pos_emb = a.pos_emb;
             {   // causal self attention over the cache (attention.py:148-173, one query)
                 DecAttnArgs<T> s = at; s.W = W.wqkv; s.K = kc; s.V = vc; s.lmax = a.Tmax; s.len = 0;
+#ifdef TXO_PS_FUSED_SELF
+                // experiment: the q,k,v projection inside the attention tile (one stage less per layer; 96 KB of weights per pair)
+                if (l == 0) PS_ATTN(ATT_SELF, APRO_EMBED, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t);
+                else PS_ATTN(ATT_SELF, APRO_LN2, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t);
+#else
                 PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t + 1);
+#endif
             }
             {   // gated output projection + residual (attention.py:96-99,180)
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_s; g.bias = W.bo_s; g.A = lao; g.resid = lx; g.y_out = ly;
@@ -415,6 +492,14 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 const float* lg = a.dlogits + (size_t)row * a.V;
                 float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
                 float best = -3.4e38f; int bi = 0x7fffffff;
+                if (a.sample) {
+                    // the reference's default decode (decoder.py:104-108): top-k, softmax(/temp), one draw keyed by (seed; row, t) --
+                    // the same function and key as the launch path's sample_step_kernel, hence the same draw.  The wave's copy
+                    // of the row lives in the LDS the GEMM tiles use between the stage's barriers (V floats per wave).
+                    float* row_lds = reinterpret_cast<float*>(smem_all) + (size_t)(threadIdx.x >> 6) * a.V;
+                    bi = sample_row([&](int j) { return ldc_f32<true>(lg + j); }, row_lds, lo, a.V, lane, a.sample_topk, a.inv_temp,
+                                    a.seed, (unsigned)row, (unsigned)t);
+                } else {
                 if ((a.V & 3) == 0) {                          // four 16-byte pieces per lane in flight
                     const int n4 = a.V >> 2;
                     for (int base = 0; base < n4; base += 256) {
@@ -444,26 +529,40 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                     }
                 }
                 wave_argmax(best, bi);                                        // ties -> lowest index (torch.argmax)
+                }
                 if (lane == 0) {
                     a.cur_tok[row] = bi;
                     a.tokens_out[(size_t)row * a.out_stride + t] = bi;
                     if (a.eos >= 0 && bi == a.eos &&
                         __hip_atomic_load(reinterpret_cast<unsigned*>(a.eos_seen + row), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
                         __hip_atomic_store(reinterpret_cast<unsigned*>(a.eos_seen + row), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicMax(&ctl->last_first_eos[team], t);
+                        // the maximum is PERFORMED (memory-side atomic, its old value back in this lane) before the count that lets the
+                        // team declare itself done is issued.  No release / acquire here: an agent-scope fence writes back / invalidates
+                        // the XCD's L2 (5-15 us, probes/team_seam.hip), and this runs inside the position.
+                        const int prev_max = atomicMax(&ctl->last_first_eos[team], t);
+                        asm volatile("s_waitcnt vmcnt(0)" :: "v"(prev_max) : "memory");
                         __hip_atomic_fetch_add(&ctl->eos_rows[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
             }
             if (a.eos >= 0 && rank == 0 && threadIdx.x == 0) {
                 // rows counted up to the previous position are all visible here (they preceded a hand-off); this position's
-                // may or may not be -- the loop ends at most two positions late, and those positions are never returned
+                // may or may not be -- the loop ends a few positions late at most, and those positions are never returned.
+                // Teams are not synchronised with each other: when the chip-wide mask fills, another team may have produced its
+                // last first-eos at a position this team has not decoded yet.  The reference returns every row up to the position at
+                // which the LAST row of the batch first produced eos (decoder.py:115-118), so a team only stops once it has decoded
+                // that position: t >= max over teams of last_first_eos.  A team's maximum is final once its bit is in the mask (see
+                // above), and other teams' words are read with read-modify-write atomics (performed at the memory side: another
+                // XCD's L2 never serves them).
                 const unsigned n = __hip_atomic_load(&ctl->eos_rows[team], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (n >= (unsigned)nr) {
                     const unsigned bit = 1u << team;
                     const unsigned old = atomicOr(&ctl->done_mask, bit);
-                    if (((old | bit) & full_mask) == full_mask)
-                        __hip_atomic_store(&ctl->stop[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((old | bit) & full_mask) == full_mask) {
+                        int need = 0;
+                        for (int k = 0; k < nteams; ++k) need = max(need, atomicMax(&ctl->last_first_eos[k], 0));
+                        if (t >= need) __hip_atomic_store(&ctl->stop[team], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
             }
             ts.arrive();
@@ -476,6 +575,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     }
 #undef PS_GEMM
 #undef PS_ATTN
+#undef PS_WB
     if (rank == 0 && threadIdx.x == 0) ctl->steps_run[team] = t;
 }
 

@@ -102,22 +102,21 @@ __device__ inline unsigned fkey(float f) {          // order-preserving float ->
 }
 
 // The reference sampler for one step (decoder.py:104-108, utils.py:85-91): top-k filter (k = int((1-0.9)*V)),
-// softmax(logits / temp), one multinomial draw.  One wave per row, the row staged in LDS.
+// softmax(logits / temp), one multinomial draw.  One wave per row, the row staged in LDS (row_lds: V floats owned by this wave).
 //   k-th largest: bitwise bisection on order-preserving uint keys (32 counting passes);
-//   draw: u ~ Philox -> inverse CDF over the kept entries in index order (lane-contiguous chunks + wave scan).
+//   draw: u ~ Philox keyed by (seed; row, t) -> inverse CDF over the kept entries in index order (lane-contiguous chunks + wave scan).
 // Statistically equivalent to torch.multinomial (a different RNG stream), reproducible for a given seed.
-__global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
-    extern __shared__ float row_lds[];
-    const int row = blockIdx.x, lane = threadIdx.x, V = a.V;
-    const int t = a.st->t;
-    const float* lg = a.logits + (size_t)row * V;
-    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
+// Shared by sample_step_kernel (launch path) and the persistent decode kernel (persist.h; LOAD reads the logits another
+// workgroup of the same launch wrote): same operations in the same order -> the same draw for the same (seed, row, t).
+template <class Load>
+__device__ inline int sample_row(Load&& load, float* row_lds, float* lo, int V, int lane, int topk, float inv_temp,
+                                 unsigned long long seed, unsigned row, unsigned t) {
     float mx = -3.4e38f;
-    for (int j = lane; j < V; j += 64) { const float v = lg[j]; row_lds[j] = v; if (lo) lo[j] = v; mx = fmaxf(mx, v); }
+    for (int j = lane; j < V; j += 64) { const float v = load(j); row_lds[j] = v; if (lo) lo[j] = v; mx = fmaxf(mx, v); }
     mx = wave_max(mx);
     __builtin_amdgcn_s_waitcnt(0xC07F);              // own LDS writes done (single wave)
     // k-th largest key
-    const int k = min(max(a.topk, 1), V);
+    const int k = min(max(topk, 1), V);
     unsigned prefix = 0u;
     for (int bit = 31; bit >= 0; --bit) {
         const unsigned cand = prefix | (1u << bit);
@@ -142,7 +141,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
         const unsigned key = fkey(v);
         bool keep = key > prefix;
         if (key == prefix && eq_left > 0) { keep = true; --eq_left; }
-        const float p = keep ? expf((v - mx) * a.inv_temp) : 0.f;
+        const float p = keep ? expf((v - mx) * inv_temp) : 0.f;
         row_lds[j] = p;                               // this lane owns [j0, j1)
         psum += p;
     }
@@ -150,8 +149,8 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const float v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     const float total = __shfl(incl, 63, 64);
-    unsigned c[4] = {(unsigned)row, (unsigned)t, 0u, 0u};
-    philox4x32(c, (unsigned)a.seed, (unsigned)(a.seed >> 32));
+    unsigned c[4] = {row, t, 0u, 0u};
+    philox4x32(c, (unsigned)seed, (unsigned)(seed >> 32));
     const float u = ((c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);    // (0, 1)
     const float target = u * total;
     // the lane whose inclusive prefix first reaches the target holds the sample
@@ -165,10 +164,20 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     pick = __shfl(pick, owner, 64);
     if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max
         float best = -3.4e38f; int bi = 0x7fffffff;
-        for (int j = lane; j < V; j += 64) { const float v = lg[j]; if (v > best) { best = v; bi = j; } }
+        for (int j = lane; j < V; j += 64) { const float v = load(j); if (v > best) { best = v; bi = j; } }
         wave_argmax(best, bi);
         pick = bi;
     }
+    return pick;
+}
+
+__global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
+    extern __shared__ float row_lds[];
+    const int row = blockIdx.x, lane = threadIdx.x, V = a.V;
+    const int t = a.st->t;
+    const float* lg = a.logits + (size_t)row * V;
+    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
+    const int pick = sample_row([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
     if (lane == 0) commit_token(a, row, t, pick);
 }
 

@@ -310,6 +310,7 @@ class AutoRegressiveDecoder(nn.Module):
                  **kwargs) -> torch.Tensor:
         enc = kwargs.pop("enc", None)
         mask = kwargs.pop("mask", None)
+        return_logits = bool(kwargs.pop("return_logits", False))   # build extension: also the logits every token was picked from
         if kwargs:
             raise ValueError(f"unsupported arguments: {sorted(kwargs)}")
         if enc is None:
@@ -331,12 +332,16 @@ class AutoRegressiveDecoder(nn.Module):
         try:
             fits = T0 + max_len - 1 <= self.max_len
             if fits and T0 == 1 and bool((st == eng.dims.bos).all()):
-                out = eng.generate(None, max_len, eos_tok, enc=enc)
+                out = eng.generate(None, max_len, eos_tok, enc=enc, return_logits=return_logits)
+            elif return_logits:
+                raise ValueError("return_logits needs a BOS start inside the positional table (max_len <= decoder.max_len)")
             else:
                 out = self._generate_stepwise(st, eos_tok, max_len, enc)
         finally:
             if decode == "sample":
                 eng.set_sampling(False)
+        if return_logits:
+            return (out[0].squeeze(0), out[1].squeeze(0)) if squeeze else out
         return out.squeeze(0) if squeeze else out
 
     def _generate_stepwise(self, st, eos_tok, max_len, enc):
@@ -435,12 +440,10 @@ class OCRModel(nn.Module):
             return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
         if decode == "greedy" and self.bos_token == self._engine.dims.bos and max_len <= self.decoder.max_len:
             return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
-        if return_logits:
-            raise ValueError("return_logits needs greedy decoding inside the positional table (max_len <= decoder.max_len)")
         enc = self.encoder(src)
         start = torch.full((src.shape[0], 1), self.bos_token, dtype=torch.int64, device=src.device)   # ocr_model.py:57
         return self.decoder.generate(start_tokens=start, eos_tok=self.eos_token, max_len=max_len, temp=temp,
-                                     decode=decode, generator=generator, seed=seed, enc=enc)
+                                     decode=decode, generator=generator, seed=seed, enc=enc, return_logits=return_logits)
 
     def forward(self, *a, **k):
         raise NotImplementedError("OCRModel.forward is the training loss (ocr_model.py:38-44); this engine "
