@@ -123,6 +123,28 @@ def cpu_baseline(dims, sd_np, a):
                        "sample": f"oracle KV-cached mode, {bc} images, all {T} steps, {dtc:.1f} s wall"}}
 
 
+def make_step(dist_on, generate_no_eos, generate_default, imgs, max_len, eos, bos, global_batch, expect_full=True):
+    """One benchmark step = one pass of the hot path over one batch.
+
+    Under torch.distributed (also with one rank) every rank decodes ITS images to max_len with the eos test off
+    (generate_no_eos(images, max_len) -> (b, max_len) tokens), ONE all-gather of the token ids follows, and the reference's
+    GLOBAL eos break (decoder.py:115-116) is applied to the gathered batch (texocr_amd/dist.py: sharded_generate).  Without
+    a process group it is model.generate() itself.  tests/test_host_cpu.py runs this very function on two gloo ranks with the
+    oracle as the per-rank generator."""
+    from texocr_amd.dist import sharded_generate
+
+    def step(i):
+        if dist_on:
+            toks = sharded_generate(generate_no_eos, imgs[i & 1], max_len, eos, bos=bos, images_are_local=True,
+                                    global_batch=global_batch, force_collective=True)
+        else:
+            toks = generate_default(imgs[i & 1], max_len)                # eos never fires for every row with random weights
+        if expect_full and toks.shape[1] != max_len:
+            raise RuntimeError(f"expected {max_len} decode steps, got {toks.shape[1]}")
+        return toks
+    return step
+
+
 def timed(model, img, max_len, warm, steps):
     import torch
     for _ in range(warm):
@@ -191,7 +213,6 @@ def main():
     from texocr_amd.config import Dims
     from texocr_amd import synth
     from texocr_amd.model import model_from_dims
-    from texocr_amd.dist import sharded_generate
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,17 +237,8 @@ def main():
     imgs = [torch.rand((a.batch, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
             for _ in range(2)]
 
-    def step(i):
-        if dist_on:
-            # every rank decodes its 64 images to max_len with the eos test off; ONE all-gather of the token ids; the
-            # reference's GLOBAL eos break is applied to the gathered batch (texocr_amd/dist.py)
-            toks = sharded_generate(lambda x, n: eng.generate(x, n, None), imgs[i & 1], a.max_len, dims.eos, bos=dims.bos,
-                                    images_are_local=True, global_batch=a.batch * world, force_collective=True)
-        else:
-            toks = model.generate(imgs[i & 1], a.max_len)                # eos never fires for every row with random weights
-        if toks.shape[1] != a.max_len:
-            raise RuntimeError(f"expected {a.max_len} decode steps, got {toks.shape[1]}")
-        return toks
+    step = make_step(dist_on, lambda x, n: eng.generate(x, n, None), model.generate, imgs, a.max_len, dims.eos, dims.bos,
+                     a.batch * world)
 
     if not a.no_roofline and rank == 0:
         eng.profile(3); eng.profile(2); eng.profile(0)          # creates the event pools now, outside the timed region

@@ -806,6 +806,50 @@ def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
     assert m._engine.query(0) == 1 and torch.equal(tp2, tl)
 
 
+@pytest.mark.parametrize("held_cus,hold_ms", [(96, 80), (200, 80), (128, 1)])
+def test_persistent_decode_under_real_cu_contention(held_cus, hold_ms):
+    """The persistent launch needs its 256 workgroups co-resident.  A second stream holds `held_cus` compute units (a spin kernel
+    with a whole CU's LDS per block, txo_debug_hold_cus) while generate() runs: for 80 ms -- twenty times the hand-off time-out, so
+    the resident workgroups give up, the launch ends as soon as the rest have started and seen the fail word, and launches take
+    over beside the filler -- or for 1 ms, which the launch simply waits out.  Tokens and logits equal the undisturbed launch
+    path's either way, nothing hangs, the fall-back is counted, and the engine goes back to the persistent launch afterwards."""
+    import os, time
+    import ctypes as C
+    from texocr_amd import _lib
+    lib = _lib.load()
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=5, dtype="bf16", max_batch=32)
+    g = torch.Generator(device="cuda").manual_seed(12)
+    img = torch.rand((32, 3, 64, 224), generator=g, device="cuda")
+    os.environ["TXO_PERSIST"] = "0"
+    try:
+        tl, ll = m.generate(img, 48, return_logits=True)
+    finally:
+        os.environ.pop("TXO_PERSIST")
+    side = torch.cuda.Stream()
+    before = m._engine.query(1)
+    os.environ["TXO_PERSIST"] = "1"
+    try:
+        torch.cuda.synchronize()
+        _lib.check(lib.txo_debug_hold_cus(held_cus, 160 * 1024, hold_ms * 1000, C.c_void_p(side.cuda_stream)))
+        time.sleep(0.002)                                       # the filler is on its CUs before the decode launch is enqueued
+        t0 = time.perf_counter()
+        tp, lp = m.generate(img, 48, return_logits=True)
+        dt = time.perf_counter() - t0
+        side.synchronize()
+        fell_back = m._engine.query(1) - before
+        print(f"held {held_cus} CUs for {hold_ms} ms: generate took {dt * 1e3:.1f} ms, fall-backs {fell_back}, persistent={m._engine.query(0)}")
+        assert torch.equal(tp, tl) and torch.equal(lp, ll)
+        assert dt < 0.5, "generate() must not hang on a busy GPU"
+        if hold_ms >= 40:
+            assert fell_back == 1 and m._engine.query(0) == 0, "co-residency was impossible: the launch must have given up"
+            assert dt < 0.060, "the give-up must not wait for the filler to finish"
+        tp2, lp2 = m.generate(img, 48, return_logits=True)      # idle GPU again: persistent, same result
+        assert m._engine.query(0) == 1 and torch.equal(tp2, tl) and torch.equal(lp2, ll)
+    finally:
+        os.environ.pop("TXO_PERSIST")
+
+
 def test_persistent_decode_global_eos_break():
     """Small vocabulary so that eos fires at different positions in different rows and teams: the persistent launch must
     return exactly the columns of the reference's GLOBAL break (decoder.py:115-116), like the launch path and the oracle."""

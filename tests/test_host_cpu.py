@@ -286,3 +286,70 @@ def test_sharded_generate_bucketed_gloo_world2(beam):
     for chunk in plan1:
         assert len({lens[i] for i in chunk}) == 1
     assert all(5 in r for r in got[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's own step composition on two gloo ranks (the N > 1 path of the benchmark, without GPUs)
+# ------------------------------------------------------------------------------------------------
+_BENCH_DIMS = dict(canvas=64, in_channels=3, embed_dim=64, enc_heads=2, enc_layers=1, dec_heads=2, dec_layers=1, vocab=16,
+                   max_len=24, bos=14, eos=5, pad=15)
+
+
+def _bench_step_worker(rank, world, port, per_rank, eos, q):
+    import importlib.util
+    import torch.distributed as dist
+    from oracle import cpu_ref
+    from texocr_amd.config import Dims
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        d = Dims(**_BENCH_DIMS)
+        sd = cpu_ref.to_torch_sd(synth.synth_state_dict(d, 11))
+        torch.set_num_threads(2)
+        # the rank's own images, as bench.py draws them (seed + rank)
+        imgs = [torch.from_numpy(synth.synth_images(per_rank, 3, 32, 48, seed=100 + rank + 10 * k)) for k in range(2)]
+        step = bench.make_step(True, lambda x, n: cpu_ref.generate_cached(sd, x, d.bos, None, n), None, imgs, 24, eos, d.bos,
+                               per_rank * world, expect_full=False)
+        out = [step(i).numpy() for i in range(2)]
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_composition_gloo_world2():
+    """bench.py --gpus N (N > 1): every rank decodes its shard with the eos test off, ONE all-gather, the GLOBAL break on the
+    gathered batch.  Two gloo ranks running bench.make_step with the oracle as the per-rank generator must return, on every
+    rank, what ONE process returns for the concatenated batch with the reference's eos break -- for an eos that breaks early
+    and for one that never fires for all rows."""
+    import torch.multiprocessing as mp
+    from oracle import cpu_ref
+    d = Dims(**_BENCH_DIMS)
+    sd = cpu_ref.to_torch_sd(synth.synth_state_dict(d, 11))
+    per_rank, world = 3, 2
+    both = [torch.cat([torch.from_numpy(synth.synth_images(per_rank, 3, 32, 48, seed=100 + r + 10 * k)) for r in range(world)]) for k in range(2)]
+    free = cpu_ref.generate_cached(sd, both[0], d.bos, None, 24).numpy()
+    common = [t for t in range(d.vocab) if (free == t).any(axis=1).all()]
+    assert common, "no token emitted by every row: pick another weight seed"
+    never = [t for t in range(d.vocab) if not (free == t).any()]
+    cases = [common[0]] + never[:1]
+    ctx = mp.get_context("spawn")
+    for ci, eos in enumerate(cases):
+        q = ctx.Queue()
+        port = 29800 + ci + os.getpid() % 150
+        procs = [ctx.Process(target=_bench_step_worker, args=(r, world, port, per_rank, eos, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for k in range(2):
+            want = cpu_ref.generate_cached(sd, both[k], d.bos, eos, 24).numpy()       # one process, the reference's break
+            for r in range(world):
+                assert np.array_equal(got[r][k], want), (eos, k, r, got[r][k].shape, want.shape)
+        if eos == common[0]:
+            assert got[0][0].shape[1] < 24, "the crafted eos must break early"

@@ -1235,6 +1235,15 @@ struct Engine : EngineBase {
     }
 };
 
+// txo_debug_hold_cus: a workgroup that keeps its CU (its LDS allocation) until the real-time counter has advanced
+__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
+    extern __shared__ unsigned hold_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    hold_lds[threadIdx.x] = threadIdx.x;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+    if (hold_lds[threadIdx.x] == 0xffffffffu) *sink = 1u;       // never true: keeps the LDS allocation alive
+}
+
 static int validate(const txo_config& c) {
     if (c.canvas_h <= 0 || c.canvas_h % 16 || c.canvas_w <= 0 || c.canvas_w % 16)
         return fail(TXO_E_INVALID, "canvas height/width must be positive multiples of 16");
@@ -1346,6 +1355,17 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out) {
     if (!e || !out) return fail(TXO_E_INVALID, "null argument");
     return e->impl->query(what, out);
+}
+
+int txo_debug_hold_cus(int32_t blocks, int32_t lds_bytes, int32_t microseconds, void* stream) {
+    if (blocks < 1 || blocks > 4096 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || microseconds < 1 || microseconds > 2000000)
+        return fail(TXO_E_INVALID, "txo_debug_hold_cus: blocks in [1, 4096], lds_bytes in [1 KiB, 160 KiB], microseconds in [1, 2e6]");
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+        return fail(TXO_E_HIP, "txo_debug_hold_cus: dynamic LDS size refused");
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)microseconds * 100ull,
+                       (unsigned*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 const char* txo_last_error(void) { return g_err.c_str(); }
