@@ -84,12 +84,22 @@ int txo_decode_begin(txo_engine* e, const float* enc_dev, int32_t B, int32_t N, 
 int txo_decode_step(txo_engine* e, const int64_t* tok_in_dev, int32_t t, float* logits_out_dev,
                     int64_t* tok_out_dev, void* stream);
 
+/* Transformer.forward over a whole prefix in ONE pass (reference model/decoder.py:41-67: token + position embedding, the
+ * decoder stack with a causal self attention, final LayerNorm, logits for EVERY position) -- the multi-position form of
+ * txo_decode_step.  tokens_dev: int64 [B][t] row-major (B = the batch of the session opened by txo_decode_begin), positions
+ * 0..t-1, 1 <= t <= cfg.max_len.  logits_out_dev: float [B][t][vocab] or NULL.  Side effect: the self-attention K/V cache holds
+ * rows 0..t-1 afterwards, so txo_decode_step(e, tok, t, ...) continues behind it.  This is what decoder.net(x, mask, enc=) maps to
+ * (teacher-forced logits), and what the sliding window of AutoRegressiveDecoder.generate (decoder.py:99-100) costs per token. */
+int txo_decode_prefill(txo_engine* e, const int64_t* tokens_dev, int32_t t, float* logits_out_dev, void* stream);
+
 /* OCRModel.generate (ocr_model.py:46-66) + AutoRegressiveDecoder.generate (decoder.py:77-122), greedy:
  * encode, then up to max_len steps; stops early only when EVERY row contains `eos` (pass eos < 0 for
  * eos_tok=None).  tokens_out_dev is [B, max_len] int64 (row stride max_len); *n_steps_out (HOST) receives
  * the number of valid columns -- the reference returns output[:, :n_steps].  logits_out_dev (may be
- * NULL) is [B, max_len, vocab].  Requires max_len <= cfg.max_len (the reference would slide its window,
- * decoder.py:99-100, which a KV cache cannot reproduce).  Synchronises the stream before returning. */
+ * NULL) is [B, max_len, vocab].  max_len may exceed cfg.max_len: the reference then slides its window (decoder.py:99-100:
+ * every further token sees the last cfg.max_len tokens at positions re-indexed from 0) and so does this call -- the first
+ * cfg.max_len positions through the KV cache, each later token through one multi-position forward of its window
+ * (txo_decode_prefill's pass).  Synchronises the stream before returning. */
 int txo_generate(txo_engine* e, const float* img_dev, int32_t B, int32_t C, int32_t H, int32_t W,
                  int32_t max_len, int32_t eos, int64_t* tokens_out_dev, int32_t* n_steps_out,
                  float* logits_out_dev, void* stream);

@@ -158,8 +158,10 @@ def test_eos_global_break_golden():
 
 
 def test_sliding_window_matches_reference():
-    """max_len > decoder.max_len: the reference slides its window (decoder.py:99-100).  The facades follow it by re-running
-    the window through the cached path for every further token; the one-call C entry point (txo_generate) still refuses."""
+    """max_len > decoder.max_len: the reference slides its window (decoder.py:99-100).  The one-call C entry point (txo_generate)
+    follows it -- the first max_length positions through the KV cache, every later token through one multi-position forward of
+    its window (txo_decode_prefill's pass) -- on both decode paths, and so do the facades."""
+    import os
     meta, g = load_golden("sliding_window")
     d, sd, m = build(meta)
     img = images(meta).cuda()
@@ -167,15 +169,86 @@ def test_sliding_window_matches_reference():
     t = m.generate(img, meta["max_len"])
     assert t.shape == (1, meta["max_len"])
     assert np.array_equal(t.cpu().numpy(), g["tokens"])
-    # the same through decoder.generate with explicit start tokens
+    # straight through the C entry point, with logits, persistent launch and launches
+    for mode in ("1", "0"):
+        os.environ["TXO_PERSIST"] = mode
+        try:
+            tk, lg = m._engine.generate(img, meta["max_len"], d.eos, return_logits=True)
+        finally:
+            os.environ.pop("TXO_PERSIST")
+        assert np.array_equal(tk.cpu().numpy(), g["tokens"]) and lg.shape == (1, meta["max_len"], d.vocab)
+        assert bool((lg.argmax(-1) == tk).all())
+    # the same through decoder.generate with explicit start tokens, and with a longer start prefix (general stepwise form)
     enc = m.encoder(img)
     start = torch.full((1, 1), d.bos, dtype=torch.int64, device="cuda")
     t2 = m.decoder.generate(start, d.eos, meta["max_len"], enc=enc)
     assert np.array_equal(t2.cpu().numpy(), g["tokens"])
-    with pytest.raises(ValueError, match="slide"):
-        m._engine.generate(img, meta["max_len"], d.eos)
+    pre = torch.cat([start, t[:, :3]], 1)
+    t3 = m.decoder.generate(pre, d.eos, meta["max_len"] - 3, enc=enc)
+    assert np.array_equal(t3.cpu().numpy(), g["tokens"][:, 3:])
     with pytest.raises(ValueError, match="slide|position"):
         m._engine.decode_step(d.max_len, torch.zeros(1, dtype=torch.int64, device="cuda"))
+    # an eos inside the slid part: the GLOBAL break looks at the whole output (decoder.py:115), window or not
+    late = int(g["tokens"][0, d.max_len + 3])
+    if late not in g["tokens"][0, :d.max_len + 3].tolist():
+        m.eos_token = late
+        tb = m.generate(img, meta["max_len"])
+        assert tb.shape[1] == d.max_len + 4 and np.array_equal(tb.cpu().numpy(), g["tokens"][:, :d.max_len + 4])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_prefill_equals_cached_steps_and_continues(dtype, monkeypatch):
+    """txo_decode_prefill: decoder.net() over a whole prefix in one causal pass.  Against t single-position cached steps of the
+    same engine (fp32: < 2e-5, i.e. summation-order noise; bf16: bf16 noise), batch 5 x 40 positions at 224x224 and the benchmark
+    width (589 keys); and the K/V cache it leaves behind continues with txo_decode_step exactly like the cache the steps built."""
+    d = Dims(canvas=672)
+    d, sd, m = build(d, seed=6, dtype=dtype, max_batch=5, max_tokens=589)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for W in (224, 672):
+        img = torch.rand((5, 3, 224, W), generator=g, device="cuda")
+        toks, step_logits = m.generate(img, 41, return_logits=True)
+        enc = m.encoder(img)
+        prefix = torch.cat([torch.full((5, 1), d.bos, dtype=torch.int64, device="cuda"), toks[:, :39]], 1)   # 40 positions
+        lp = m.decoder.net(prefix, enc=enc)                                   # one pass
+        monkeypatch.setenv("TXO_NET_STEPWISE", "1")
+        ls = m.decoder.net(prefix, enc=enc)                                   # 40 cached steps
+        monkeypatch.delenv("TXO_NET_STEPWISE")
+        err = float((lp - ls).abs().max())
+        print(f"prefill vs steps ({dtype}, width {W}): max |dlogit| {err:.2e}")
+        assert lp.shape == (5, 40, d.vocab)
+        assert err < (2e-5 if dtype == "fp32" else 0.08)
+        if dtype == "fp32":
+            assert float((lp - step_logits[:, :40]).abs().max()) < 2e-5 and bool((lp.argmax(-1) == toks[:, :40]).all())
+        # continue behind the prefill: position 40 fed with token 39 gives the logits of the free-running decode
+        m._engine.decode_begin(enc)
+        m._engine.decode_prefill(prefix, want_logits=False)
+        l40, _ = m._engine.decode_step(40, toks[:, 39].contiguous())
+        assert float((l40 - step_logits[:, 40]).abs().max()) < (2e-5 if dtype == "fp32" else 0.08)
+
+
+def test_prefill_net_is_an_order_of_magnitude_faster_than_steps(monkeypatch):
+    """decoder.net() on 4 x 256 tokens: one multi-position pass against 256 single-position steps driven from Python."""
+    import time
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=0, max_batch=4)
+    img = torch.from_numpy(synth.synth_images(4, 3, 224, 224, seed=1234)).cuda()
+    enc = m.encoder(img)
+    prefix = torch.randint(0, d.vocab - 3, (4, 256), device="cuda")
+    prefix[:, 0] = d.bos
+
+    def clock(n):
+        m.decoder.net(prefix, enc=enc); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = m.decoder.net(prefix, enc=enc)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, out
+    fast, a = clock(5)
+    monkeypatch.setenv("TXO_NET_STEPWISE", "1")
+    slow, b = clock(2)
+    print(f"decoder.net 4x256: one pass {fast * 1e3:.2f} ms, 256 steps {slow * 1e3:.2f} ms ({slow / fast:.1f}x)")
+    assert float((a - b).abs().max()) < 5e-5
+    assert slow / fast >= 10
 
 
 def test_hybrid_resnet_embedder_golden():

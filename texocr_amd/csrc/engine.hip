@@ -23,6 +23,7 @@
 #include "gemm_big.h"
 #include "gemm_pp.h"
 #include "persist.h"
+#include "prefill.h"
 #include "rows.h"
 #include "step.h"
 
@@ -64,6 +65,7 @@ struct EngineBase {
     virtual int encode(const float* img, int B, int C, int H, int W, float* enc_out, hipStream_t s) = 0;
     virtual int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) = 0;
     virtual int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) = 0;
+    virtual int decode_prefill(const int64_t* tokens, int t, float* logits_out, hipStream_t s) = 0;
     virtual int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                          int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) = 0;
     virtual int generate_beam(const float* img, const float* enc, int B, int C, int H, int W, int N, int beams, int max_len,
@@ -99,7 +101,8 @@ template <typename T>
 struct Engine : EngineBase {
     // ----- device weights -----
     std::vector<void*> allocs;
-    struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr; };
+    struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr;
+                   T* wo16 = nullptr; float* bo16 = nullptr; };   // decoder: second copy interleaved by 16 (prefill: the large-GEMM epilogues)
     struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr;
                   T* w1_16 = nullptr; float* b1_16 = nullptr; };   // decoder, wide rows: second copy interleaved by 16 (large-batch FFN-in)
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
@@ -111,7 +114,7 @@ struct Engine : EngineBase {
     bool hybrid = false;
     float *enc_g = nullptr, *enc_b = nullptr, *encn_g = nullptr, *encn_b = nullptr, *enc_gb = nullptr;   // enc_gb: gamma then beta (GEMM epilogues)
     std::vector<AttnW> enc_attn; std::vector<MlpW> enc_mlp;
-    float *tok_emb = nullptr, *pos_emb = nullptr, *dec_g = nullptr, *dec_b = nullptr, *decn_g = nullptr, *decn_b = nullptr;
+    float *tok_emb = nullptr, *pos_emb = nullptr, *dec_g = nullptr, *dec_b = nullptr, *decn_g = nullptr, *decn_b = nullptr, *dec_gb = nullptr;
     T* wlog = nullptr; float* blog = nullptr; T* wckv = nullptr;
     std::vector<AttnW> dec_self, dec_cross; std::vector<MlpW> dec_mlp;
     // ----- workspace -----
@@ -276,6 +279,10 @@ struct Engine : EngineBase {
             if (int r = upload_T(&w->wqkv, cat)) return r;
         }
         if (int r = upload_T(&w->wo, interleave(wo->data, D, inner, G))) return r;
+        if (G != 16) {                                        // decoder: the prefill runs these projections on the encoder-side GEMMs
+            if (int r = upload_T(&w->wo16, interleave(wo->data, D, inner, 16))) return r;
+            if (int r = upload_f32(&w->bo16, interleave(bo->data, D, 1, 16))) return r;
+        }
         return upload_f32(&w->bo, interleave(bo->data, D, 1, G));
     }
     int load_mlp(const std::string& p, int F, MlpW* w, int G) {
@@ -285,7 +292,7 @@ struct Engine : EngineBase {
         if (int r = upload_T(&w->w1, interleave(w1->data, F, D, G))) return r;
         if (int r = upload_f32(&w->b1, interleave(b1->data, F, 1, G))) return r;
         if (int r = upload_T(&w->w2, w2->data)) return r;
-        if (sizeof(T) == 2 && G == 8 && D >= 512) {       // see enqueue_step: FFN-in of wide decoders at >= 128 rows goes through the large-GEMM kernel
+        if (G == 8) {       // decoder: the prefill's FFN-in; also enqueue_step: FFN-in of wide bf16 decoders at >= 128 rows goes through the large-GEMM kernel
             if (int r = upload_T(&w->w1_16, interleave(w1->data, F, D, 16))) return r;
             if (int r = upload_f32(&w->b1_16, interleave(b1->data, F, 1, 16))) return r;
         }
@@ -364,6 +371,8 @@ struct Engine : EngineBase {
         {   // weights arena: fp32 size of everything handed in is an upper bound for both storage types
             size_t bytes = 0;
             for (auto& kv : host) bytes += kv.second.data.size() * sizeof(float) + 512;
+            // + the decoder's second (16-interleaved) copies of the gated projections for the prefill
+            bytes += (size_t)cfg.dec_layers * ((size_t)2 * 2 * D * Id + (size_t)2 * Fd * D + 4 * D + 2 * Fd + 4096) * sizeof(float);
             if (int r = arena_begin(bytes + (1u << 20))) return r;
         }
         const int npos = 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
@@ -405,6 +414,12 @@ struct Engine : EngineBase {
         if (!(t = get("decoder.net.pos_embedding.embedding.weight", {Tmax, D}))) return TXO_E_STATE;
         if (int r = upload_f32(&pos_emb, t->data)) return r;
         if (int r = shared_ln("decoder.net.attn_layers", 3 * c.dec_layers, &dec_g, &dec_b)) return r;
+        {
+            std::vector<float> gb(get("decoder.net.attn_layers.layers.0.0.weight", {D})->data);
+            const std::vector<float>& bb = get("decoder.net.attn_layers.layers.0.0.bias", {D})->data;
+            gb.insert(gb.end(), bb.begin(), bb.end());
+            if (int r = upload_f32(&dec_gb, gb)) return r;
+        }
         dec_self.resize(c.dec_layers); dec_cross.resize(c.dec_layers); dec_mlp.resize(c.dec_layers);
         std::vector<float> kv_concat;
         for (int l = 0; l < c.dec_layers; ++l) {
@@ -467,9 +482,10 @@ struct Engine : EngineBase {
         if (int r = dalloc(&ez, M * D)) return r;
         if (int r = dalloc(&eenc, M * D)) return r;
         if (int r = dalloc(&enc_t, M * D)) return r;
-        if (int r = dalloc(&eqkv, 3 * M * Ie)) return r;
-        if (int r = dalloc(&eao, M * Ie)) return r;
-        if (int r = dalloc(&ehid, M * Fe)) return r;
+        // (the prefill of the decoder runs in the encoder's workspace: sized for the wider of the two stacks)
+        if (int r = dalloc(&eqkv, 3 * M * Imax)) return r;
+        if (int r = dalloc(&eao, M * Imax)) return r;
+        if (int r = dalloc(&ehid, M * Fmax)) return r;
         if (int r = dalloc(&ckv, (size_t)c.dec_layers * 2 * M * Id)) return r;
         if (int r = dalloc(&skv, (size_t)c.dec_layers * 2 * Bmax * Id * Tmax)) return r;
         if (int r = dalloc(&dx, (size_t)Bmax * D)) return r;
@@ -810,7 +826,7 @@ struct Engine : EngineBase {
                 dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
-                if (sizeof(T) == 2 && nb >= 128 && dec_mlp[l].w1_16) {
+                if (sizeof(T) == 2 && D >= 512 && nb >= 128 && dec_mlp[l].w1_16) {
                     // perf mode, wide rows (ViT-Base decoder: 768), >= 128 rows: the 16-row launch would be 3072 blocks that each
                     // redo the LayerNorm sandwich of their rows (39 us); one LayerNorm launch + the 128x128 GEMM takes ~15 us.
                     // (fp32 parity mode keeps the 16-row kernel at every batch size: a row's bits never depend on the batch.)
@@ -904,6 +920,80 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    int decode_prefill(const int64_t* tokens, int t, float* logits_out, hipStream_t s) override {
+        if (n_lanes != 1) return fail(TXO_E_STATE, "decode_prefill needs a session started by txo_decode_begin");
+        if (sImg != sB) return fail(TXO_E_STATE, "decode_prefill is not available inside a beam-search session");
+        lanes[0].stream = s;
+        return prefill(tokens, t, t, logits_out, nullptr, s);
+    }
+
+    // ---- multi-position decoder forward (prefill.h): Transformer.forward over t positions at once, filling the self K/V cache ----
+    // tokens [B][tok_stride] (the first t of each row); logits_out [B][t][V] or null; last_logits [B][V] or null (final LN + logits of
+    // position t-1 only, on the single-position launch).  Runs in the encoder's workspace, image chunks of as many rows as fit.
+    template <typename TO>
+    void launch_attn_mq(hipStream_t s, bool causal, const T* q, const T* k, const T* v, TO* out, int nb, int nq, int nk, int kv_rows) {
+        const dim3 grid((nq + EA_QBLK - 1) / EA_QBLK, nb * cfg.dec_heads);
+        if (causal) hipLaunchKernelGGL((attn_mq_kernel<T, TO, true>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads);
+        else hipLaunchKernelGGL((attn_mq_kernel<T, TO, false>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads);
+    }
+    int prefill(const int64_t* tokens, int tok_stride, int t, float* logits_out, float* last_logits, hipStream_t s) {
+        if (!session) return fail(TXO_E_STATE, "txo_decode_begin has not been called");
+        if (t < 1 || t > Tmax) return fail(TXO_E_INVALID, "prefill length outside the decoder's positional table");
+        if (V % 8) return fail(TXO_E_INVALID, "prefill needs a vocabulary size that is a multiple of 8");
+        const size_t cap = (size_t)Bmax * Nmax;               // rows of the encoder workspace
+        if ((size_t)t > cap) return fail(TXO_E_INVALID, "prefill: one prefix does not fit the engine's workspace (max_batch * max_tokens rows)");
+        const int B = sB, N = sN, heads = cfg.dec_heads;
+        const int bc = (int)std::min<size_t>(B, cap / t);     // images per chunk
+        const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)sImg * N * Id;
+        T* qbuf = reinterpret_cast<T*>(eqkv);
+        for (int b0 = 0; b0 < B; b0 += bc) {
+            const int nb = std::min(bc, B - b0), M = nb * t;
+            {
+                const size_t n4 = (size_t)M * (D / 4);
+                hipLaunchKernelGGL(embed_rows_kernel, dim3((n4 + 255) / 256), dim3(256), 0, s, tokens + (size_t)b0 * tok_stride, tok_stride,
+                                   tok_emb, pos_emb, ex, M, t, D, V);
+            }
+            for (int l = 0; l < cfg.dec_layers; ++l) {
+                // the shared-LN sandwich exactly as in encode(): x = LN(y) is never written, the GEMM epilogues rebuild it
+                const ResidLN res_x{ey, estats, dec_gb, D}, res_first{ex, nullptr, nullptr, D};
+                if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, dec_g, dec_b, M);
+                else launch_ln<3, T>(s, ey, estats, ez, dec_g, dec_b, M);
+                T* kc = skv + (size_t)(2 * l) * self_stride + (size_t)b0 * heads * Tmax * DH;
+                T* vc = skv + (size_t)(2 * l + 1) * self_stride + (size_t)b0 * heads * Tmax * DH;
+                gemm_plain(s, ez, dec_self[l].wqkv, M, 3 * Id, D, EpiHeadsKV<T>{qbuf, kc, vc, Id, heads, t, Tmax});
+                launch_attn_mq<T>(s, true, qbuf, kc, vc, eao, nb, t, t, Tmax);
+                gemm_plain(s, eao, dec_self[l].wo16, M, 2 * D, Id, EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, dec_self[l].bo16});
+                // cross attention over the cached encoder projections (attention.py:114-126: k, v from the raw encoder output)
+                launch_ln<3, T>(s, ey, estats, ez, dec_g, dec_b, M);
+                gemm_plain(s, ez, dec_cross[l].wq, M, Id, D, EpiHeads<T>{qbuf, 0, Id, heads, t});
+                const T* ck = ckv + (size_t)(2 * l) * cross_stride + (size_t)(b0 / std::max(1, sB / sImg)) * heads * N * DH;
+                const T* cv = ckv + (size_t)(2 * l + 1) * cross_stride + (size_t)(b0 / std::max(1, sB / sImg)) * heads * N * DH;
+                launch_attn_mq<T>(s, false, qbuf, ck, cv, eao, nb, t, N, N);
+                gemm_plain(s, eao, dec_cross[l].wo16, M, 2 * D, Id, EpiGluRes<sizeof(T) == 2>{ey, res_x, dec_cross[l].bo16});
+                // GeGLU feed-forward
+                launch_ln<3, T>(s, ey, estats, ez, dec_g, dec_b, M);
+                gemm_plain(s, ez, dec_mlp[l].w1_16, M, 2 * Fd, D, EpiGeglu<T>{ehid, dec_mlp[l].b1_16, Fd});
+                gemm_plain(s, ehid, dec_mlp[l].w2, M, D, Fd, EpiBiasRes{ey, res_x, dec_mlp[l].b2});
+            }
+            if (logits_out) {                                 // decoder.py:57-60 over every position
+                launch_ln<2, T>(s, ey, nullptr, ez, decn_g, decn_b, M);
+                gemm_plain(s, ez, wlog, M, V, D, EpiStore<float>{logits_out + (size_t)b0 * t * V, V, blog});
+            }
+            if (last_logits) {                                // the last position only: the step path's final-LN + logits launch on gathered rows
+                hipLaunchKernelGGL(gather_last_rows_kernel, dim3((nb * D + 255) / 256), dim3(256), 0, s, ey, dy + (size_t)b0 * D, nb, t, D);
+            }
+        }
+        if (last_logits) {
+            DecGemmArgs<T> f{};
+            f.rows = B; f.D = D; f.inner = Id; f.heads = heads; f.tmax = Tmax; f.t_host = t - 1; f.t_ptr = &st[0].t;
+            f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.logits = last_logits; f.y = dy; f.gamma = decn_g; f.beta = decn_b;
+            step_host_t = t - 1;
+            if (int r = launch_dec_gemm<PRO_LNF, EPI_LOGITS>(s, f)) return r;
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
     // ---- the decode loop as ONE persistent launch (persist.h) -------------------------------------------------------
     // Which decode path?  TXO_PERSIST=1 / 0 forces the persistent launch on / off (where it exists: decoder width 256 with 8
     // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
@@ -940,7 +1030,9 @@ struct Engine : EngineBase {
         return 0;
     }
     // returns 0 (done), TXO_E_STATE (the launch gave up: redo with launches), or an error
-    int generate_persist(int B, int N, int max_len, int eos, int64_t* tokens_out, float* logits_out, int* n_steps, hipStream_t s) {
+    // n_pos positions are decoded; rows of tokens_out / logits_out are out_stride positions apart
+    int generate_persist(int B, int N, int n_pos, int out_stride, int eos, int64_t* tokens_out, float* logits_out, int* n_steps, hipStream_t s) {
+        const int max_len = n_pos;
         PersistArgs<T> pa{};
         pa.B = B; pa.N = N; pa.V = V; pa.Ld = cfg.dec_layers; pa.Tmax = Tmax; pa.max_len = max_len; pa.eos = eos; pa.bos = cfg.bos;
         for (int l = 0; l < cfg.dec_layers; ++l) {
@@ -954,7 +1046,7 @@ struct Engine : EngineBase {
         pa.dx = dx; pa.dy = dy; pa.dq = dq; pa.dlogits = dlogits; pa.dao = dao; pa.dhid = dhid;
         pa.cur_tok = cur_tok; pa.eos_seen = eos_seen; pa.skv = skv; pa.ckv = ckv;
         pa.self_stride = (size_t)sB * Id * Tmax; pa.cross_stride = (size_t)sImg * N * Id;
-        pa.tokens_out = tokens_out; pa.out_stride = max_len; pa.logits_out = logits_out;
+        pa.tokens_out = tokens_out; pa.out_stride = out_stride; pa.logits_out = logits_out;
         pa.sample = sample_mode; pa.sample_topk = sample_topk; pa.inv_temp = 1.0f / sample_temp; pa.seed = sample_seed;
         pa.ctl = pctl; pa.stamps = pstamps;
         const char* stamp_file = getenv("TXO_PSTAMPS");
@@ -1041,9 +1133,10 @@ struct Engine : EngineBase {
     int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                  int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) override {
         if (max_len < 1) return fail(TXO_E_INVALID, "max_len must be >= 1");
-        if (max_len > Tmax)
-            return fail(TXO_E_INVALID, "max_len exceeds the decoder's max_length: the reference would slide its window "
-                                       "(decoder.py:99-100), which the KV-cached path does not reproduce");
+        // max_len > decoder.max_len: the reference slides its window (decoder.py:99-100).  The first Tmax positions decode with the
+        // KV cache as always (n_pos of them; rows of the outputs are max_len apart); every further token re-runs its window of the
+        // last Tmax tokens, positions re-indexed from 0, through ONE multi-position forward (prefill) -- generate_window below.
+        const int n_pos = std::min(max_len, Tmax);
         if (img) {
             if (int r = encode(img, B, C, H, W, eenc, s)) return r;
             enc = eenc; N = 1 + (H / 16) * (W / 16);
@@ -1052,8 +1145,13 @@ struct Engine : EngineBase {
         last_persist = false;
         if (persist_usable(B)) {
             int steps = 0;
-            const int pr = generate_persist(B, N, max_len, eos, tokens_out, logits_out, &steps, s);
-            if (pr == 0) { last_persist = true; if (n_steps) *n_steps = steps; return 0; }
+            const int pr = generate_persist(B, N, n_pos, max_len, eos, tokens_out, logits_out, &steps, s);
+            if (pr == 0) {
+                last_persist = true;
+                if (steps == n_pos && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
+                if (n_steps) *n_steps = steps;
+                return 0;
+            }
             if (pr != TXO_E_STATE) return pr;
             ++persist_fallbacks;                                  // placement check or a bounded spin gave up: decode with launches
             set_lanes(1, s);
@@ -1080,7 +1178,7 @@ struct Engine : EngineBase {
             for (int i = 1; i < n_lanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
         }
         int64_t* tdst = use_graph ? tok_buf : tokens_out;
-        const int tstride = use_graph ? Tmax : max_len;
+        const int tstride = use_graph ? Tmax : max_len;               // rows of tokens_out are max_len apart (only n_pos positions are decoded here)
         // GLOBAL eos break (decoder.py:115-116): the device records done_flag[t]; the host looks at the flags of every 32 steps.
         // The look must not drain the stream: the flags of a chunk are copied to pinned memory behind the chunk, a few more
         // steps are enqueued, and only then the host waits for that copy -- the GPU keeps running those steps meanwhile (a
@@ -1088,7 +1186,7 @@ struct Engine : EngineBase {
         // a break at most AHEAD extra steps have run; their tokens lie beyond `steps` and are never returned.
         const int CHUNK = 32, AHEAD = 4;
         int* flags = flags_host;                                   // pinned, allocated in init()
-        int steps = max_len;
+        int steps = n_pos;
         look_failed = false;
         int pend_lo = -1, pend_hi = -1;                            // chunk whose flags are in flight to the host
         auto look = [&]() -> bool {                                // wait for the pending chunk's flags; true = all rows done
@@ -1103,8 +1201,8 @@ struct Engine : EngineBase {
         };
         const char* stamp_file = getenv("TXO_STAMPS");
         if (stamp_file && !stamp_buf) { if (int r = dalloc(&stamp_buf, (size_t)STAMP_KERNELS * STAMP_BLOCKS * 3)) return r; }
-        const int stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
-        for (int t = 0; t < max_len; ++t) {
+        const int stamp_step = stamp_file ? std::min(n_pos - 1, 200) : -1;
+        for (int t = 0; t < n_pos; ++t) {
             if (t == stamp_step) { HIP_TRY(hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_KERNELS * STAMP_BLOCKS * 3, s)); stamp_slot = 0; stamp_names.clear(); }
             else if (stamp_slot >= 0) dump_stamps(stamp_file, s);
             for (int i = 0; i < n_lanes; ++i) {
@@ -1112,8 +1210,8 @@ struct Engine : EngineBase {
                 else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos, nullptr, t)) return r2;
             }
             if (eos < 0) continue;
-            if (pend_lo >= 0 && (t == pend_hi + AHEAD || t + 1 == max_len)) { if (look()) break; if (look_failed) return TXO_E_HIP; }
-            if ((t + 1) % CHUNK == 0 || t + 1 == max_len) {
+            if (pend_lo >= 0 && (t == pend_hi + AHEAD || t + 1 == n_pos)) { if (look()) break; if (look_failed) return TXO_E_HIP; }
+            if ((t + 1) % CHUNK == 0 || t + 1 == n_pos) {
                 const int lo = (t / CHUNK) * CHUNK;
                 for (int i = 0; i < n_lanes; ++i) {
                     HIP_TRY(hipMemcpyAsync(flags + (size_t)i * Tmax + lo, done_flag + (size_t)i * Tmax + lo,
@@ -1121,7 +1219,7 @@ struct Engine : EngineBase {
                     HIP_TRY(hipEventRecord(ev_flags[i], lanes[i].stream));
                 }
                 pend_lo = lo; pend_hi = t;
-                if (t + 1 == max_len) { (void)look(); if (look_failed) return TXO_E_HIP; }
+                if (t + 1 == n_pos) { (void)look(); if (look_failed) return TXO_E_HIP; }
             }
         }
         // join the lanes back into the caller's stream
@@ -1131,11 +1229,43 @@ struct Engine : EngineBase {
         }
         if (use_graph)
             HIP_TRY(hipMemcpy2DAsync(tokens_out, sizeof(int64_t) * max_len, tok_buf, sizeof(int64_t) * Tmax,
-                                     sizeof(int64_t) * max_len, B, hipMemcpyDeviceToDevice, s));
+                                     sizeof(int64_t) * n_pos, B, hipMemcpyDeviceToDevice, s));
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
         set_lanes(1, s);
+        if (steps == n_pos && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
         if (n_steps) *n_steps = steps;
+        return 0;
+    }
+
+    // The reference beyond its positional table (decoder.py:97-116 with :99-100 active): token i >= Tmax comes from the window
+    // output[:, -Tmax:] = tokens i-Tmax .. i-1 at positions 0 .. Tmax-1 (BOS has left the window), the whole window through the
+    // decoder, the last position's logits.  Nothing cached survives the shift, so every such token costs one multi-position
+    // forward of Tmax rows per image (prefill) + the single-position final LayerNorm / logits / token selection of the step path.
+    // The GLOBAL eos test still looks at the whole output (:115), i.e. the per-row "seen" state carries over.
+    int generate_window(int B, int n_pos, int max_len, int eos, int64_t* tokens_out, float* logits_out, int* steps, hipStream_t s) {
+        set_lanes(1, s);
+        lanes[0].stream = s;
+        // the launch path's eos bookkeeping, rebuilt from the tokens decoded so far (a persistent launch keeps its own)
+        HIP_TRY(hipMemsetAsync(st, 0, sizeof(StepState), s));
+        hipLaunchKernelGGL(rebuild_eos_state_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tokens_out, max_len, n_pos, B, eos, cfg.bos,
+                           eos_seen, &st[0].rows_with_eos);
+        int* flag = done_flag;                                    // ONE flag, rewritten per token (commit_token indexes it with the token index)
+        for (int i = n_pos; i < max_len; ++i) {
+            if (int r = prefill(tokens_out + (i - Tmax), max_len, Tmax, nullptr, dlogits, s)) return r;
+            hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, i);
+            StepArgs sa{dlogits, V, B, cur_tok, tokens_out, max_len, logits_out, st, eos_seen, flag - i, eos, sample_topk, 1.0f / sample_temp, sample_seed};
+            if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(64), (size_t)V * sizeof(float), s, sa);
+            else hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
+            *steps = i + 1;
+            if (eos >= 0) {                                       // slow path: one host look per token
+                HIP_TRY(hipMemcpyAsync(flags_host, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_TRY(hipStreamSynchronize(s));
+                if (flags_host[0]) break;
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipGetLastError());
         return 0;
     }
 
@@ -1318,6 +1448,11 @@ int txo_decode_begin(txo_engine* e, const float* enc, int32_t B, int32_t N, void
 int txo_decode_step(txo_engine* e, const int64_t* tok_in, int32_t t, float* logits_out, int64_t* tok_out, void* stream) {
     if (!e) return fail(TXO_E_INVALID, "null engine");
     return e->impl->decode_step(tok_in, t, logits_out, tok_out, (hipStream_t)stream);
+}
+
+int txo_decode_prefill(txo_engine* e, const int64_t* tokens, int32_t t, float* logits_out, void* stream) {
+    if (!e || !tokens) return fail(TXO_E_INVALID, "null argument");
+    return e->impl->decode_prefill(tokens, t, logits_out, (hipStream_t)stream);
 }
 
 int txo_generate(txo_engine* e, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t max_len,

@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import re
 from typing import Dict, Optional
 
@@ -140,6 +141,11 @@ class HipEngine:
     def decode_begin(self, enc: torch.Tensor) -> None:
         self._ensure()
         torch.ops.texocr.decode_begin(enc, self.id)
+
+    def decode_prefill(self, tokens: torch.Tensor, want_logits: bool = True) -> Optional[torch.Tensor]:
+        """All positions of a prefix in one pass (txo_decode_prefill); the K/V cache then holds rows 0..t-1."""
+        logits = torch.ops.texocr.decode_prefill(tokens, self.id, bool(want_logits))
+        return logits if want_logits else None
 
     def decode_step(self, t: int, tok_in: Optional[torch.Tensor] = None, want_logits: bool = True):
         logits, nxt = torch.ops.texocr.decode_step(tok_in, self.id, int(t), int(self._B), bool(want_logits))
@@ -260,8 +266,8 @@ class VisionEncoder(nn.Module):
 
 
 class Transformer(nn.Module):
-    """model.decoder.net: (B,t) int64 tokens -> (B,t,V) logits over the whole prefix (decoder.py:41-67).
-    Implemented as t KV-cached steps, which equals the reference's full-prefix causal forward."""
+    """model.decoder.net: (B,t) int64 tokens -> (B,t,V) logits over the whole prefix (decoder.py:41-67): ONE causal
+    multi-position pass (txo_decode_prefill), which also leaves the K/V cache filled for the positions given."""
 
     def __init__(self, engine: HipEngine, _shared: Optional[dict] = None):
         super().__init__()
@@ -283,8 +289,10 @@ class Transformer(nn.Module):
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
         eng.decode_begin(enc)
+        if eng.dims.vocab % 8 == 0 and os.environ.get("TXO_NET_STEPWISE") is None:
+            return eng.decode_prefill(x)
         out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
-        xt = x.t().contiguous()                                   # one contiguous token row per position
+        xt = x.t().contiguous()                                   # fallback (odd vocabulary sizes; tests): one cached step per position
         for t in range(x.shape[1]):
             out[:, t] = eng.decode_step(t, xt[t])[0]
         return out
@@ -330,8 +338,7 @@ class AutoRegressiveDecoder(nn.Module):
             eng.set_sampling(True, temp=temp, seed=seed)
             self._resample = (temp, seed)
         try:
-            fits = T0 + max_len - 1 <= self.max_len
-            if fits and T0 == 1 and bool((st == eng.dims.bos).all()):
+            if T0 == 1 and bool((st == eng.dims.bos).all()):
                 out = eng.generate(None, max_len, eos_tok, enc=enc, return_logits=return_logits)
             elif return_logits:
                 raise ValueError("return_logits needs a BOS start inside the positional table (max_len <= decoder.max_len)")
@@ -365,8 +372,11 @@ class AutoRegressiveDecoder(nn.Module):
             if output.shape[1] > L:
                 valid = 0                                          # every position shifted: nothing cached is reusable
             wt = window.t().contiguous()
-            for p in range(valid, n - 1):
-                eng.decode_step(p, wt[p], want_logits=False)
+            if n - 1 - valid > 1 and eng.dims.vocab % 8 == 0:
+                eng.decode_prefill(window[:, :n - 1].contiguous(), want_logits=False)   # positions 0..n-2 in one pass
+            else:
+                for p in range(valid, n - 1):
+                    eng.decode_step(p, wt[p], want_logits=False)
             if self._resample is not None and output.shape[1] > L:
                 # the device sampler draws from a counter RNG keyed by (seed, row, position); once the window slides the
                 # position stays at L - 1, so the seed advances with the token index instead
@@ -438,7 +448,8 @@ class OCRModel(nn.Module):
             if max_len > self.decoder.max_len:
                 raise ValueError(f"beam search needs max_len <= decoder.max_len ({self.decoder.max_len})")
             return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
-        if decode == "greedy" and self.bos_token == self._engine.dims.bos and max_len <= self.decoder.max_len:
+        if decode == "greedy" and self.bos_token == self._engine.dims.bos:
+            # (max_len > decoder.max_len: txo_generate slides the window like the reference, decoder.py:99-100)
             return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
         enc = self.encoder(src)
         start = torch.full((src.shape[0], 1), self.bos_token, dtype=torch.int64, device=src.device)   # ocr_model.py:57

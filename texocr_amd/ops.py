@@ -140,6 +140,30 @@ def _(tok_in, engine, t, batch, want_logits):
             ref.new_empty((batch,), dtype=torch.int64))
 
 
+@custom_op("texocr::decode_prefill", mutates_args=())
+def decode_prefill(tokens: torch.Tensor, engine: int, want_logits: bool) -> torch.Tensor:
+    """Transformer.forward over a whole prefix in one pass (decoder.py:41-67): tokens (B, t) int64 at positions 0..t-1 ->
+    logits (B, t, V) (or (0, t, V)); fills the self-attention K/V cache rows 0..t-1 of the session opened by decode_begin."""
+    e = _eng(engine)
+    B = getattr(e, "_B", None)
+    if tokens.ndim != 2 or tokens.dtype != torch.int64 or not tokens.is_cuda or tokens.shape[0] != B:
+        raise ValueError("tokens must be an int64 GPU tensor of shape (B, t) matching the session started by texocr::decode_begin")
+    if tokens.device.index != e.device:
+        raise ValueError(f"tokens live on cuda:{tokens.device.index} but the engine was created on cuda:{e.device}")
+    tokens = tokens.contiguous()
+    t = tokens.shape[1]
+    logits = torch.empty((B if want_logits else 0, t, e.dims.vocab), device=tokens.device, dtype=torch.float32)
+    with torch.cuda.device(e.device):
+        _lib.check(e.lib.txo_decode_prefill(e.handle, tokens.data_ptr(), int(t), logits.data_ptr() if want_logits else None, _stream()))
+    return logits
+
+
+@decode_prefill.register_fake
+def _(tokens, engine, want_logits):
+    d = _eng(engine).dims
+    return tokens.new_empty((tokens.shape[0] if want_logits else 0, tokens.shape[1], d.vocab), dtype=torch.float32)
+
+
 def _gen_outputs(src, e, max_len, want_logits):
     B = src.shape[0]
     toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
