@@ -379,8 +379,9 @@ def test_bf16_mode_logits_error_bounded():
     print(f"cfg1 bf16 vs reference fixture, teacher-forced 4x64: max |dlogit| over the reference's top-5 {err:.4f}, top-1 agreement {agree:.4f}")
     # measured on MI355X: max |dlogit| ~0.04 on logits spanning about [-3, 3], agreement ~0.98 (disagreements sit on the
     # thinnest margins of this random-weight model: the fixture's smallest top-1/top-2 margin is 1e-4)
-    assert err < 0.1, err
-    assert agree > 0.95, agree                               # teacher-forced top-1 agreement
+    # bounds = ~1.5x the measurements (r03, the one-pass decoder forward: 0.023 / 1.000; r02, single-position steps: 0.029-0.04 / 0.98-0.996)
+    assert err < 0.06, err
+    assert agree > 0.97, agree                               # teacher-forced top-1 agreement
 
 
 # ------------------------------------------------------------------------------------------------
@@ -681,8 +682,15 @@ def test_multipass_attention_panels():
     d2, sd2, mb = build(d, seed=11, dtype="bf16", max_batch=2)
     encb = mb.encoder(img.cuda())
     prefix = torch.cat([torch.full((2, 1), d.bos, dtype=torch.long, device="cuda"), toks[:, :-1]], 1)
-    lb = mb.decoder.net(prefix[:, :280], enc=encb).cpu()
-    assert float((lb - ref_l[:, :280]).abs().max()) < 0.3
+    import os
+    os.environ["TXO_NET_STEPWISE"] = "1"            # the single-position kernels' multi-pass panels are what this test is about
+    try:
+        lb = mb.decoder.net(prefix[:, :280], enc=encb).cpu()
+    finally:
+        os.environ.pop("TXO_NET_STEPWISE")
+    errb = float((lb - ref_l[:, :280]).abs().max())
+    print(f"multi-pass panels, bf16 steps vs oracle (64-d toy, 280 positions): max |dlogit| {errb:.4f}")
+    assert errb < 0.04                              # measured 0.025
 
 
 def test_large_ragged_batch_rows_independent():
@@ -763,11 +771,19 @@ def test_wide_decoder_large_batch_ffn_path():
     tf, lf = mf.generate(img, 10, return_logits=True)
     prefix = torch.cat([torch.full((130, 1), d.bos, dtype=torch.long, device="cuda"), tf[:, :-1]], 1)
     enc_big = mb.encoder(img)
-    lb_big = mb.decoder.net(prefix, enc=enc_big)                       # 130 rows: large-batch path
-    lb_small = mb.decoder.net(prefix[:64], enc=enc_big[:64])          # 64 rows: 16-row kernel
-    assert float((lb_big[:64] - lb_small).abs().max()) < 0.05
-    assert float((lb_big.float() - lf).abs().max()) < 0.35
-    assert float((lb_big[:64].argmax(-1) == lb_small.argmax(-1)).float().mean()) > 0.97
+    import os
+    os.environ["TXO_NET_STEPWISE"] = "1"            # single-position steps: the launch path's FFN-in routing is what this test is about
+    try:
+        lb_big = mb.decoder.net(prefix, enc=enc_big)                       # 130 rows: large-batch path
+        lb_small = mb.decoder.net(prefix[:64], enc=enc_big[:64])          # 64 rows: 16-row kernel
+    finally:
+        os.environ.pop("TXO_NET_STEPWISE")
+    e1, e2 = float((lb_big[:64] - lb_small).abs().max()), float((lb_big.float() - lf).abs().max())
+    a1 = float((lb_big[:64].argmax(-1) == lb_small.argmax(-1)).float().mean())
+    print(f"wide decoder FFN routes: 130-row vs 64-row bf16 max |dlogit| {e1:.4f} (top-1 agreement {a1:.4f}); bf16 vs fp32 {e2:.4f}")
+    assert e1 < 0.02                                # measured 0.013
+    assert e2 < 0.05                                # measured 0.033
+    assert a1 > 0.99                                # measured 0.998
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1037,7 +1053,7 @@ def test_cfg4_vit_base_golden():
     agree = float((tb.cpu().numpy() == g["tokens"]).mean())
     lerr = float(np.abs(lb.cpu().numpy() - g["step_logits"]).max())
     print(f"cfg4 bf16 vs reference: free-running token agreement {agree:.3f} over 2x8, max |dlogit| {lerr:.3f} (fixture margin >= 0.032)")
-    assert lerr < 0.15 and agree >= 0.8
+    assert lerr < 0.06 and agree >= 0.93             # measured 0.037-0.042 and 16/16 (one flip in 16 allowed)
 
 
 def test_cfg4_full_size_b256():
@@ -1159,7 +1175,7 @@ def test_cfg2_full_size_bf16():
     first = float((t1[:, 0] == tf_[:, 0]).float().mean())
     print(f"cfg2 bf16 vs fp32 engine, B=64 x 64 steps: teacher-forced top-1 agreement {agree:.4f}, max |dlogit| {err:.3f}, "
           f"free-running first-token agreement {first:.3f}")
-    assert agree > 0.95 and err < 0.1
+    assert agree > 0.975 and err < 0.06              # measured 0.988 and 0.035-0.039
 
 
 def test_torch_free_c_program_on_the_c_abi(tmp_path):
