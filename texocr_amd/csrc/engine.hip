@@ -1055,7 +1055,7 @@ struct Engine : EngineBase {
         pa.poll_sleep = 1;
         if (const char* ps = getenv("TXO_PS_POLL_SLEEP")) pa.poll_sleep = atoi(ps);
         if (const char* em = getenv("TXO_PS_EARLY")) pa.early_mask = atoi(em);
-        pa.poll_mode = 0;                                         // scalar-load polls (persist.h: TeamSync::poll)
+        pa.poll_mode = 3;                                         // scalar polls behind s_dcache_inv (persist.h: TeamSync::poll; -1.3 % per generate against vector polls)
         if (const char* pm = getenv("TXO_PS_POLL")) pa.poll_mode = atoi(pm);
         if (const char* inj = getenv("TXO_PERSIST_INJECT_FAIL")) pa.inject_fail = atoi(inj);   // tests: the give-up / fall-back path
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
