@@ -322,7 +322,7 @@ def main():
             algo_cross = a.batch * heads * 2 * N * 64 * esz                 # one cross-attention launch / stage: K and V panels once
             mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3              # dense TFLOP/s, MI355X_MICROARCH.md
             def pmc(kind):
-                for rnd in ("r02", "r01"):
+                for rnd in ("r03", "r02", "r01"):
                     fn = os.path.join("profiles", f"{rnd}_pmc_{kind}{a.dtype}_b{a.batch}.json")
                     try:
                         pm = json.load(open(os.path.join(ROOT, fn)))["traffic"]
@@ -365,7 +365,7 @@ def main():
             finally:
                 os.environ.pop("TXO_PERSIST")
             traffic, tsrc = None, None
-            for rnd in ("r02", "r01"):
+            for rnd in ("r03", "r02", "r01"):
                 fn = os.path.join("profiles", f"{rnd}_pmc_{a.dtype}_b{a.batch}.json")
                 try:
                     pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]

@@ -401,6 +401,126 @@ void dec_gemm_kernel(DecGemmArgs<T> a) {
     dec_gemm_tile<T, PRO, EPI, KW, BN, false>(a, blockIdx.x, blockIdx.y, threadIdx.x, smem, true, NoWait{});
 }
 
+// ---- >= 128 rows of a wide decoder (launch path only) ---------------------------------------------------------------------------
+// dec_gemm_tile_pf's PRO_NONE form with RT row tiles of 16 per block that SHARE the block's weight fragments: 16-row blocks
+// re-read every weight slice rows/16 times from L2 (74 MB per out-projection at 256 rows x 768), which is what bounds those
+// launches; 64-row blocks read a quarter of that.  Same K split over the four waves, same reduction order, same epilogue
+// arithmetic as the 16-row tile -> a row's bits do not depend on which of the two kernels computed it.  A separate function on
+// purpose: the 16-row tile is inlined ~20 times into the persistent decode kernel, whose code generation is sensitive to any
+// change of it (a templated-in RT = 1 cost that kernel 3 %).
+template <typename T, int EPI, int KW, int BN, int RT>
+__device__ __forceinline__ void dec_gemm_wide_tile(const DecGemmArgs<T>& a, int bx, int by, int tid, unsigned char* smem) {
+    constexpr bool PAIRED = EPI == EPI_GLU_RES || EPI == EPI_GEGLU;
+    constexpr bool TWO = BN == 32;
+    constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
+    static_assert(KW > 0, "compile-time K only");
+    constexpr int GROUP = KW > 16 ? DG_GROUP : KW;            // k-chunks a wave keeps in flight at once
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lg = lane >> 4;
+    const int m0 = by * DG_BM * RT, n0 = bx * BN;
+    constexpr int K = KW * 4 * KCH;
+    const int rows = a.rows;
+    const int em0 = m0 + lg * 4 + wave;                       // output row of this thread in row tile 0 (row tile rt: + 16 rt)
+    const int na = n0 + lr, nb = n0 + 16 + lr;
+    float e_b0 = 0.f, e_b1 = 0.f, e_res0[RT], e_res1[RT];
+    if constexpr (PAIRED) { e_b0 = a.bias[na]; if constexpr (TWO) e_b1 = a.bias[nb]; }
+    else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_LOGITS) { e_b0 = a.bias[min(na, a.N - 1)]; e_b1 = a.bias[min(nb, a.N - 1)]; }
+    const T* w0 = a.W + (size_t)min(na, a.N - 1) * K + lg * PER16;
+    const T* w1 = a.W + (size_t)min(nb, a.N - 1) * K + lg * PER16;
+    u32x4 fw0[GROUP], fw1[GROUP], fa[RT][GROUP];
+    auto load_group = [&](int g0) {
+#pragma unroll
+        for (int c = 0; c < GROUP; ++c) {
+            const int kc = wave + 4 * (g0 + c);
+            fw0[c] = ld16(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16(w1 + kc * KCH);
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int m = min(m0 + rt * DG_BM + lr, rows - 1);
+#pragma unroll
+            for (int c = 0; c < GROUP; ++c) fa[rt][c] = ld16(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+        }
+    };
+    load_group(0);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int emc = min(em0 + rt * DG_BM, rows - 1);
+        e_res0[rt] = 0.f; e_res1[rt] = 0.f;
+        if constexpr (EPI == EPI_GLU_RES) {
+            e_res0[rt] = a.resid[(size_t)emc * a.D + (n0 >> 1) + (lr & 7)];
+            if constexpr (TWO) e_res1[rt] = a.resid[(size_t)emc * a.D + (n0 >> 1) + 8 + (lr & 7)];
+        } else if constexpr (EPI == EPI_BIAS_RES) {
+            e_res0[rt] = a.resid[(size_t)emc * a.D + min(na, a.N - 1)]; e_res1[rt] = a.resid[(size_t)emc * a.D + min(nb, a.N - 1)];
+        }
+    }
+    int t = 0;
+    if constexpr (EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
+    __builtin_amdgcn_sched_barrier(0);                        // every fragment load ahead of the first MFMA (see dec_gemm_tile_pf)
+    f32x4 acc0[RT], acc1[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { acc0[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[rt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int g0 = 0; g0 < KW; g0 += GROUP) {
+        if (g0 > 0) load_group(g0);
+#pragma unroll
+        for (int c = 0; c < GROUP; ++c)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) { mma16<T>(acc0[rt], fa[rt][c], fw0[c]); if constexpr (TWO) mma16<T>(acc1[rt], fa[rt][c], fw1[c]); }
+    }
+    float* red = reinterpret_cast<float*>(smem);              // [rt][wave][half][reg][lane]
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[rt * 2048 + ((wave * 2 + 0) * 4 + r) * 64 + lane] = acc0[rt][r];
+                                      red[rt * 2048 + ((wave * 2 + 1) * 4 + r) * 64 + lane] = acc1[rt][r]; }
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { c0 += red[rt * 2048 + ((w * 2 + 0) * 4 + wave) * 64 + lane]; c1 += red[rt * 2048 + ((w * 2 + 1) * 4 + wave) * 64 + lane]; }
+        const int em = em0 + rt * DG_BM;
+        if constexpr (PAIRED) {
+#pragma unroll
+            for (int h = 0; h < (TWO ? 2 : 1); ++h) {
+                const float mine = (h ? c1 : c0) + (h ? e_b1 : e_b0);
+                const float gate = dpp_mov<DPP_ROR8>(mine);
+                if (lr < 8 && em < rows) {
+                    const int j = (n0 >> 1) + 8 * h + lr;
+                    if constexpr (EPI == EPI_GLU_RES) a.y_out[(size_t)em * a.D + j] = mine * sigmoid_sel<sizeof(T) == 2>(gate) + (h ? e_res1[rt] : e_res0[rt]);
+                    else a.h_out[(size_t)em * a.F + j] = Elem<T>::from_f32(mine * gelu_sel<sizeof(T) == 2>(gate));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < (TWO ? 2 : 1); ++h) {
+                const int n = h ? nb : na;
+                const float v = h ? c1 : c0;
+                if (n >= a.N || em >= rows) continue;
+                if constexpr (EPI == EPI_QKV) {
+                    const int which = n / a.inner, f = n - which * a.inner;
+                    if (which == 0) a.q_out[(size_t)em * a.inner + f] = v;
+                    else {
+                        T* cache = (which == 1) ? a.k_cache : a.v_cache;
+                        cache[(((size_t)em * a.heads + (f >> 6)) * a.tmax + t) * DH + (f & 63)] = Elem<T>::from_f32(v);
+                    }
+                } else if constexpr (EPI == EPI_BIAS_RES) {
+                    a.y_out[(size_t)em * a.D + n] = v + (h ? e_b1 : e_b0) + (h ? e_res1[rt] : e_res0[rt]);
+                } else {
+                    a.logits[(size_t)em * a.N + n] = v + (h ? e_b1 : e_b0);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int EPI, int KW, int BN, int RT>
+__global__ __launch_bounds__(256, 1) void dec_gemm_wide_kernel(DecGemmArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    dec_gemm_wide_tile<T, EPI, KW, BN, RT>(a, blockIdx.x, blockIdx.y, threadIdx.x, smem);
+}
+
 template <typename T>
 inline size_t dec_gemm_lds_bytes(int K, bool has_pro) {
     const size_t red = (size_t)4 * 2 * 4 * 64 * 4;

@@ -724,6 +724,29 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    // >= 128 rows of a wide (>= 512) bf16 decoder: the projections without a LayerNorm prologue on blocks of RT x 16 rows that share
+    // their weight fragments (dec_gemm.h: RT).  Returns false when the shape has no such instantiation (the caller launches the
+    // 16-row kernel).  A row's bits do not depend on RT (same K split over the waves, same reduction order).
+    template <int EPI>
+    bool launch_dec_gemm_wide(hipStream_t s, DecGemmArgs<T> a) {
+        if constexpr (sizeof(T) != 2) { (void)s; (void)a; return false; }
+        else {
+            if (a.rows < 128 || D < 512 || getenv("TXO_DEC_WIDE_OFF")) return false;
+            constexpr int KCH = Elem<T>::KCHUNK;
+            const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
+            a.stamps = nullptr;
+#define TXO_DGW(KW_, BN_, RT_)                                                                                              \
+            do {                                                                                                            \
+                const dim3 grid((a.N + BN_ - 1) / BN_, (a.rows + DG_BM * RT_ - 1) / (DG_BM * RT_)), blk(256);                 \
+                hipLaunchKernelGGL((dec_gemm_wide_kernel<T, EPI, KW_, BN_, RT_>), grid, blk, (size_t)RT_ * 8192, s, a); \
+                return true;                                                                                                \
+            } while (0)
+            if (kw == 6) TXO_DGW(6, 32, 4);                  // K = 768: the gated out-projections, FFN-in behind its LayerNorm launch
+#undef TXO_DGW
+            return false;
+        }
+    }
+
     // attention front half: (optional) row prologue + q / qkv projection + cached single-query attention
     struct AttnOpt {
         bool cross = false; int apro = APRO_LN2;
@@ -802,6 +825,8 @@ struct Engine : EngineBase {
                     a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb;
                     a.q_out = dq + r0 * Id;
                     a.k_cache = kc + r0 * cfg.dec_heads * Tmax * DH; a.v_cache = vc + r0 * cfg.dec_heads * Tmax * DH;
+                    // (one LayerNorm launch + the projection on 64-row blocks, as the out-projections and FFN-in below do at >= 128
+                    // rows of a wide decoder, measured the same 17.7 us as this fused launch at 256 x 768: not used here)
                     if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_QKV>(s, a) : launch_dec_gemm<PRO_LN2, EPI_QKV>(s, a))) return r;
                     o.apro = APRO_NONE;
                 } else {
@@ -811,7 +836,7 @@ struct Engine : EngineBase {
                 dbg(s, "self attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_self[l].wo; g.bias = dec_self[l].bo; g.A = lao;
                 g.resid = lx; g.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r;
+                if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
                 dbg(s, "self out", l);
             }
             {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
@@ -822,7 +847,7 @@ struct Engine : EngineBase {
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
                 g.resid = lx; g.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r;
+                if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
                 dbg(s, "cross out", l);
             }
             {   // GeGLU feed-forward
@@ -831,7 +856,10 @@ struct Engine : EngineBase {
                     // redo the LayerNorm sandwich of their rows (39 us); one LayerNorm launch + the 128x128 GEMM takes ~15 us.
                     // (fp32 parity mode keeps the 16-row kernel at every batch size: a row's bits never depend on the batch.)
                     launch_ln<1>(s, ly, lx, dz + r0 * D, dec_g, dec_b, nb);
-                    launch_gemm_big<T>(s, LoadPlain<T>{dz + r0 * D, D}, dec_mlp[l].w1_16, nb, 2 * Fd, D, EpiGeglu<T>{lhid, dec_mlp[l].b1_16, Fd});
+                    DecGemmArgs<T> w = base; w.N = 2 * Fd; w.K = D; w.W = dec_mlp[l].w1; w.bias = dec_mlp[l].b1; w.A = dz + r0 * D;
+                    w.h_out = lhid; w.F = Fd;
+                    if (!launch_dec_gemm_wide<EPI_GEGLU>(s, w))
+                        launch_gemm_big<T>(s, LoadPlain<T>{dz + r0 * D, D}, dec_mlp[l].w1_16, nb, 2 * Fd, D, EpiGeglu<T>{lhid, dec_mlp[l].b1_16, Fd});
                 } else {
                     DecGemmArgs<T> a = base; a.N = 2 * Fd; a.K = D; a.W = dec_mlp[l].w1; a.bias = dec_mlp[l].b1; a.y = ly; a.x_out = lx;
                     a.h_out = lhid; a.F = Fd;
@@ -840,7 +868,7 @@ struct Engine : EngineBase {
                 dbg(s, "ffn1", l);
                 DecGemmArgs<T> g = base; g.N = D; g.K = Fd; g.W = dec_mlp[l].w2; g.bias = dec_mlp[l].b2; g.A = lhid;
                 g.resid = lx; g.y_out = ly;
-                if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, g)) return r;
+                if (int r = launch_dec_gemm<PRO_NONE, EPI_BIAS_RES>(s, g)) return r;   // (64-row blocks at K = 3072: 18.1 vs 18.3 us, not used)
             }
         }
         DecGemmArgs<T> f = base; f.N = V; f.K = D; f.W = wlog; f.bias = blog; f.logits = llog;
