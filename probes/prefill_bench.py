@@ -33,4 +33,4 @@ for dtype in ("fp32", "bf16"):
     m.eos_token = None
     inside = clock(lambda: m.generate(img, 64), 3)
     beyond = clock(lambda: m.generate(img, 96), 3)
-    print(f"sliding window {dtype} B=16, table 64: 64 tokens {inside*1e3:.2f} ms, 96 tokens {beyond*1e3:.2f} ms -> {(beyond-inside)/32*1e3:.0f} us per token beyond the table", flush=True)
+    print(f"sliding window {dtype} B=16, table 64: 64 tokens {inside*1e3:.2f} ms, 96 tokens {beyond*1e3:.2f} ms -> {(beyond-inside)/32*1e6:.0f} us per token beyond the table", flush=True)
