@@ -109,7 +109,7 @@ __device__ inline unsigned fkey(float f) {          // order-preserving float ->
 // Shared by sample_step_kernel (launch path) and the persistent decode kernel (persist.h; LOAD reads the logits another
 // workgroup of the same launch wrote): same operations in the same order -> the same draw for the same (seed, row, t).
 template <class Load>
-__device__ inline int sample_row(Load&& load, float* row_lds, float* lo, int V, int lane, int topk, float inv_temp,
+__device__ __attribute__((noinline)) int sample_row_lds(Load&& load, float* row_lds, float* lo, int V, int lane, int topk, float inv_temp,
                                  unsigned long long seed, unsigned row, unsigned t) {
     float mx = -3.4e38f;
     for (int j = lane; j < V; j += 64) { const float v = load(j); row_lds[j] = v; if (lo) lo[j] = v; mx = fmaxf(mx, v); }
@@ -169,6 +169,103 @@ __device__ inline int sample_row(Load&& load, float* row_lds, float* lo, int V, 
         pick = bi;
     }
     return pick;
+}
+
+// The same sampler with the row in REGISTERS (vocabularies up to 64 * SR_PER entries): the LDS form above spends ~30 us per row in
+// dependent LDS round trips (32 bisection passes x 16 strided reads per lane); here every lane keeps its SR_PER consecutive logits,
+// a bisection pass counts with one ballot + scalar popcount per register slot (the count is wave-uniform, no cross-lane sum), and the
+// bisection stops at the first candidate that separates exactly k entries (any threshold with k entries at or above it gives the same
+// kept set).  Same kept set, same probabilities summed in the same order, same counter RNG key -> the SAME draw as the LDS form.
+#ifndef TXO_SAMPLER_LDS
+#define TXO_SAMPLER_LDS 0      // 1: build the LDS form only (tests of its equality with the register form: probes/ab_libs.sh)
+#endif
+constexpr int SR_PER = 16;
+template <class Load>
+__device__ __attribute__((noinline)) int sample_row_regs(Load&& load, float* lo, int V, int lane, int topk, float inv_temp,
+                                                         unsigned long long seed, unsigned row, unsigned t) {
+    // (noinline: inlined into the persistent decode kernel its 16-register row pushed that kernel into scratch)
+    const int per = (V + 63) / 64, j0 = lane * per;           // the LDS form's lane-contiguous chunks [j0, j1)
+    // ONE register array: the order-preserving keys (a logit is recovered from its key by unfkey)
+    auto unfkey = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
+    unsigned key[SR_PER];
+    float mx = -3.4e38f;
+#pragma unroll
+    for (int u = 0; u < SR_PER; ++u) {
+        const int j = j0 + u;
+        const bool in = u < per && j < V;
+        const float v = in ? load(min(j, V - 1)) : 0.f;
+        if (in) { if (lo) lo[j] = v; mx = fmaxf(mx, v); }
+        key[u] = in ? fkey(v) : 0u;                           // 0 lies below every real key
+    }
+    mx = wave_max(mx);
+    const int k = min(max(topk, 1), V);
+    unsigned prefix = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned cand = prefix | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) cnt += (int)__builtin_popcountll(__ballot(key[u] >= cand));
+        if (cnt >= k) prefix = cand;
+        if (cnt == k) break;                                  // exactly k entries at or above cand: the kept set is fixed
+    }
+    int ngt = 0, neq = 0;
+#pragma unroll
+    for (int u = 0; u < SR_PER; ++u) { ngt += key[u] > prefix; neq += (key[u] == prefix) && (u < per && j0 + u < V); }
+    int ngt_all = wave_sum(ngt), eq_before = neq;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(eq_before, o, 64); if (lane >= o) eq_before += v; }
+    eq_before -= neq;
+    const int eq_mine = (k - ngt_all) - eq_before;            // ties this lane may keep, in index order
+    // probability of slot u (0 when not kept); `ties` = ties of this lane already passed
+    auto prob = [&](int u, int& ties) -> float {
+        const bool in = u < per && j0 + u < V;
+        bool keep = in && key[u] > prefix;
+        if (in && key[u] == prefix) { if (ties < eq_mine) keep = true; ++ties; }
+        return keep ? expf((unfkey(key[u]) - mx) * inv_temp) : 0.f;
+    };
+    float psum = 0.f;
+    {
+        int ties = 0;
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) { const float pu = prob(u, ties); if (u < per && j0 + u < V) psum += pu; }
+    }
+    float incl = psum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const float total = __shfl(incl, 63, 64);
+    unsigned c[4] = {row, t, 0u, 0u};
+    philox4x32(c, (unsigned)seed, (unsigned)(seed >> 32));
+    const float uu = ((c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);    // (0, 1)
+    const float target = uu * total;
+    const unsigned long long hit = __ballot(incl >= target && psum > 0.f);
+    const int owner = hit ? (int)__builtin_ctzll(hit) : 63;
+    int pick = -1;
+    if (lane == owner) {                              // the owner walks its chunk again (probabilities recomputed, not stored)
+        float run = incl - psum;
+        bool done = false;
+        int ties = 0;
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) {
+            const float pu = prob(u, ties);
+            if (!done && pu > 0.f) { pick = j0 + u; run += pu; if (run >= target) done = true; }
+        }
+    }
+    pick = __shfl(pick, owner, 64);
+    if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max
+        float best = -3.4e38f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) if (u < per && j0 + u < V && unfkey(key[u]) > best) { best = unfkey(key[u]); bi = j0 + u; }
+        wave_argmax(best, bi);
+        pick = bi;
+    }
+    return pick;
+}
+
+template <class Load>
+__device__ inline int sample_row(Load&& load, float* row_lds, float* lo, int V, int lane, int topk, float inv_temp,
+                                 unsigned long long seed, unsigned row, unsigned t) {
+    if (V <= 64 * SR_PER && !TXO_SAMPLER_LDS) return sample_row_regs(load, lo, V, lane, topk, inv_temp, seed, row, t);
+    return sample_row_lds(load, row_lds, lo, V, lane, topk, inv_temp, seed, row, t);
 }
 
 __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
