@@ -168,10 +168,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     // the place of its key by selects (same values in the same operations -> same bits).  A row is never requested before
     // its own position's hand-off (an early copy in this CU's L1 would outlive the append), hence nothing is early at t = 0.
     constexpr bool HIST_EARLY = COH && MODE == ATT_SELF && !FUSED && !BEAM;
-    // persistent kernel, FUSED self attention (q,k,v projected here): the cached keys are rows 0..t-1, all older than this position,
-    // and row t never leaves this tile -> the whole panel is requested before the wait
-    constexpr bool HIST_EARLY_F = COH && MODE == ATT_SELF && FUSED && !BEAM;
-    if constexpr (!KV_EARLY && !HIST_EARLY && !HIST_EARLY_F) wait_prev();
+    if constexpr (!KV_EARLY && !HIST_EARLY) wait_prev();
     int t = 0;
     if constexpr (MODE == ATT_SELF || APRO == APRO_EMBED) t = (COH || a.t_host >= 0) ? a.t_host : *a.t_ptr;
     // cached keys: fused self handles the new key t apart; plain self finds it in the cache already
@@ -210,7 +207,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
         }
     };
     [[maybe_unused]] u32x4 kt = {0u, 0u, 0u, 0u}, vt = {0u, 0u, 0u, 0u};
-    if constexpr (KV_EARLY || HIST_EARLY_F) {
+    if constexpr (KV_EARLY) {
         if (!poll_wave) issue_k(0);
         wait_prev();
         if (poll_wave) issue_k(0);

@@ -348,10 +348,6 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             ++stage;                                                                                                    \
         } while (0)
         // LK: keys of the panel (a group without a tile mirrors the tile's barriers)
-#ifndef TXO_PS_WBS
-#define TXO_PS_WBS 3
-#endif
-#define PS_WB(MODE, APRO) ((MODE) == ATT_SELF && (APRO) != APRO_NONE && sizeof(T) == 2 ? TXO_PS_WBS : 1)   /* as the launch path: engine.hip WBS */
 #define PS_ATTN(MODE, APRO, NLV, ARGS, PF, LK)                                                                          \
         do {                                                                                                            \
             const int np_ = nr * HEADS;                                                                                 \
@@ -363,10 +359,10 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                     else if (base_ == 0) {                                                                              \
                         auto args_ = ARGS;                                                                              \
                         args_.stamps = (PS_ATTN_STAMPS && ts.stp && grp == 0) ? ts.stp + 5 - 3 * p_ : nullptr;   /* tile stamps land at stp[5..7] */ \
-                        dec_attn_tile<T, MODE, APRO, NLV, PS_WB(MODE, APRO), false, false, true>(args_, p_, tid,                       \
+                        dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(args_, p_, tid,                       \
                             *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave && !((a.early_mask >> (MODE == ATT_SELF ? 0 : 1)) & 1), ts, PF); \
                     }                                                                                                   \
-                    else dec_attn_tile<T, MODE, APRO, NLV, PS_WB(MODE, APRO), false, false, true>(ARGS, p_, tid,          \
+                    else dec_attn_tile<T, MODE, APRO, NLV, 1, false, false, true>(ARGS, p_, tid,          \
                         *reinterpret_cast<DecAttnLds<false>*>(smem), true, poll_wave && !((a.early_mask >> (MODE == ATT_SELF ? 0 : 1)) & 1), ts); \
                 } else if (base_ == 0) { ts(); PF(); }                                                                  \
             }                                                                                                           \
@@ -393,10 +389,8 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             {   // LN sandwich (or token + position embedding) + q,k,v projection; k,v appended to the cache (attention.py:124-127)
                 DecGemmArgs<T> g = gb; g.N = 3 * ID; g.K = D; g.W = W.wqkv; g.y = ly; g.x_out = lx;
                 g.tok = a.cur_tok + r0; g.tok_emb = a.tok_emb; g.pos_emb = a.pos_emb; g.q_out = lq; g.k_cache = kc; g.v_cache = vc;
-#ifndef TXO_PS_FUSED_SELF
                 if (l == 0) PS_GEMM(PRO_EMBED, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
                 else PS_GEMM(PRO_LN2, EPI_QKV, KWP, 32, g, NC_QKV, PF_P, none);
-#endif
             }
             if (!placement_checked) {                         // every workgroup of the team has ORed its XCC id in by now
                 placement_checked = true;
@@ -414,13 +408,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             at.y = ly; at.x_out = lx; at.out = lao; at.qin = lq; at.tok = a.cur_tok + r0; at.tok_emb = a.tok_emb; at.pos_emb = a.pos_emb;
             {   // causal self attention over the cache (attention.py:148-173, one query)
                 DecAttnArgs<T> s = at; s.W = W.wqkv; s.K = kc; s.V = vc; s.lmax = a.Tmax; s.len = 0;
-#ifdef TXO_PS_FUSED_SELF
-                // experiment: the q,k,v projection inside the attention tile (one stage less per layer; 96 KB of weights per pair)
-                if (l == 0) PS_ATTN(ATT_SELF, APRO_EMBED, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t);
-                else PS_ATTN(ATT_SELF, APRO_LN2, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t);
-#else
                 PS_ATTN(ATT_SELF, APRO_NONE, (sizeof(T) == 2 ? 8 : 16), s, pf_os, t + 1);
-#endif
             }
             {   // gated output projection + residual (attention.py:96-99,180)
                 DecGemmArgs<T> g = gb; g.N = 2 * D; g.K = ID; g.W = W.wo_s; g.bias = W.bo_s; g.A = lao; g.resid = lx; g.y_out = ly;
@@ -575,7 +563,6 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     }
 #undef PS_GEMM
 #undef PS_ATTN
-#undef PS_WB
     if (rank == 0 && threadIdx.x == 0) ctl->steps_run[team] = t;
 }
 
