@@ -540,6 +540,9 @@ struct Engine : EngineBase {
     void conv(hipStream_t s, const T* in, const T* w, T* out, int B, int H, int W, int C, int OC, int k, int stride) {
         int OH, OW, pt, pl;
         same_pad(H, k, stride, &OH, &pt); same_pad(W, k, stride, &OW, &pl);
+        // a 1x1 stride-1 convolution on NHWC activations IS a plain row-major GEMM: [B*H*W][C] x [OC][C]^T -> the 256x256 LDS-DMA
+        // kernel where the shape fits it (bf16: the bottlenecks' expanding convolutions, 256 / 512 / 1024 output channels)
+        if (k == 1 && stride == 1 && !getenv("TXO_CONV1X1_OLD")) { gemm_plain(s, in, w, B * H * W, OC, C, EpiStore<T>{out, OC, nullptr}); return; }
         LoadConv<T> ld{in, H, W, C, stride, pt, pl, FastDiv(OH * OW), FastDiv(OW), FastDiv(C), FastDiv(k)};
         launch_gemm_big<T>(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<T>{out, OC, nullptr});
     }
