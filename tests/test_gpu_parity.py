@@ -226,6 +226,30 @@ def test_prefill_equals_cached_steps_and_continues(dtype, monkeypatch):
         assert float((l40 - step_logits[:, 40]).abs().max()) < (2e-5 if dtype == "fp32" else 0.08)
 
 
+def test_prefill_in_image_chunks_when_the_workspace_is_smaller_than_the_prefix_block(monkeypatch):
+    """The multi-position forward runs in the encoder's workspace (max_batch * max_tokens rows); a prefix block with more rows
+    than that is processed in image chunks (here 4 images x 20 positions = 80 rows against 4 x 17 = 68: chunks of 3 + 1 images).
+    Same logits as single-position steps, and as the reference's teacher-forced fixture for the first two images."""
+    meta, g = load_golden("tiny")
+    d, sd, m = build(meta, max_batch=4)
+    assert m._engine.max_batch * m._engine.max_tokens < 4 * 20
+    img2 = images(meta)
+    img = torch.cat([img2, img2.flip(0)]).cuda()                       # 4 images
+    enc = m.encoder(img)
+    toks = torch.from_numpy(g["tokens"].astype(np.int64)).cuda()
+    rows = torch.cat([toks, toks.flip(0)])
+    extra = torch.tensor([[3, 9, 27]], dtype=torch.long, device="cuda").expand(4, -1)       # causal: later tokens do not touch earlier logits
+    prefix = torch.cat([torch.full((4, 1), d.bos, dtype=torch.long, device="cuda"), rows, extra], 1)
+    assert prefix.shape == (4, 20)
+    one = m.decoder.net(prefix, enc=enc)
+    monkeypatch.setenv("TXO_NET_STEPWISE", "1")
+    steps = m.decoder.net(prefix, enc=enc)
+    assert one.shape == (4, 20, d.vocab)
+    assert float((one - steps).abs().max()) < 2e-5
+    np.testing.assert_allclose(one[:2, :16].cpu().numpy(), g["tf_logits"][:, :16], atol=3e-5)
+    np.testing.assert_allclose(one[2:, :16].flip(0).cpu().numpy(), g["tf_logits"][:, :16], atol=3e-5)
+
+
 def test_prefill_net_is_an_order_of_magnitude_faster_than_steps(monkeypatch):
     """decoder.net() on 4 x 256 tokens: one multi-position pass against 256 single-position steps driven from Python."""
     import time
