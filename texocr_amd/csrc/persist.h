@@ -20,16 +20,20 @@
 //
 // Hand-off (one per stage, all-to-all inside the team): every storing wave drains its stores (s_waitcnt vmcnt(0)),
 // workgroup barrier, ONE plain store of the stage number into the workgroup's word of the team's flag line; a consumer
-// polls that line with sc1 loads from one wave, workgroup barrier, then reads the rows with sc1 loads (never from its CU's L1, which other CUs'
-// stores do not refresh; the XCD's L2 -- the coherence point of its 32 CUs -- serves them).  Stores are plain (they stay
+// polls that line from one wave (scalar loads behind s_dcache_inv by default, or sc1 vector loads: TeamSync), workgroup barrier, then
+// reads the rows with sc1 loads (never from its CU's L1, which other CUs' stores do not refresh; the XCD's L2 -- the coherence point
+// of its 32 CUs -- serves them).  Stores are plain (they stay
 // in that L2).  This is valid only while producer and consumer share an XCD: each workgroup ORs its XCC id into a
 // per-team mask, and after the first hand-off every workgroup checks that its team's mask has ONE bit; otherwise the
-// launch gives up (ctl.fail) and the engine decodes with launches.  All spins are bounded (fail bit 0).
+// launch gives up (ctl.fail) and the engine decodes with launches.  All spins are bounded (4 ms of the real-time counter, fail bit 0;
+// the fail word is read with every scalar poll, so one team's give-up ends every team within a hand-off).
 //
 // GLOBAL eos break: a row handler counts first occurrences of eos per team; a team whose rows all contain eos sets its
-// bit in a chip-wide mask (memory-side atomic), and once the mask is full every team stops within two positions.  The
-// host derives n_steps from the per-team "position at which my last row first produced eos" exactly as the reference's
-// (output == eos).any(1).all() would; positions decoded beyond it are never returned.
+// bit in a chip-wide mask (memory-side atomic).  Teams are not synchronised with each other, so once the mask is full a team
+// stops only when it has decoded the position at which the LAST row of the batch first produced eos (the maximum over the teams'
+// last_first_eos words, final once their bits are set).  The host derives n_steps from those words exactly as the reference's
+// (output == eos).any(1).all() would, checks that every team ran that far, and never returns positions beyond it.
+// The position's last stage picks the token: arg-max, or the reference's sampler (step.h: sample_row; same draws as the launch path).
 #pragma once
 #include "dec_attn.h"
 #include "dec_gemm.h"
@@ -82,7 +86,7 @@ template <typename T> struct PersistArgs {
     int poll_sleep;                                           // TeamSync: 64-clock sleeps between two polls of the flag line
     int sample; int sample_topk; float inv_temp; unsigned long long seed;   // sample != 0: the reference's sampler ends a position (step.h: sample_row) instead of the arg-max
     int early_mask;                                           // bit 0 / 1: the POLLING wave also requests its self-attention history / its cross K panel before the wait (its poll then returns behind them)
-    int poll_mode;                                            // TeamSync::poll (0 vector sc1 loads, 1 scalar glc loads, 2 scalar loads behind s_dcache_inv)
+    int poll_mode;                                            // TeamSync::poll: 0 vector sc1 loads, 1 scalar glc loads, 2 the same behind s_dcache_inv, 3 (default) s_dcache_inv + plain scalar loads
     int inject_fail;                                          // test hook: position at which team 0 reports a hand-off time-out (0 = never)
     int stagger_ticks;                                        // experiment: team k starts k * this many 10-ns ticks late (desynchronises the teams' HBM phases)
     unsigned long long* stamps; int stamp_step;               // diagnostic: [team][PS_STAMP_RANKS][stage][5] ticks at that position (ranks 0, 10, 20, 31)
@@ -105,10 +109,12 @@ struct TeamSync {
     int rank; unsigned epoch;                                 // stages this workgroup has finished
     unsigned* fail; int* lds_dead; bool armed, dead;
     int poll_sleep;                                           // s_sleep(1) units (64 clocks) between two polls
-    // poll: 0 = one vector load of the line per poll (sc1: served by the XCD's L2); 1 = SCALAR loads with glc (forced miss in the
-    // scalar cache: also the L2's copy); 2 = scalar loads behind s_dcache_inv.  The scalar path keeps the poll out of the wave's
-    // vector-memory queue: vector loads return in order, so a wave that polls with vector loads cannot request its K/V panel or
-    // weights BEFORE the wait without the poll's data arriving behind them -- with scalar polls EVERY wave requests early.
+    // poll: 0 = one vector load of the line per poll (sc1: served by the XCD's L2); 3 (default) = s_dcache_inv + ordinary SCALAR
+    // loads (they miss the just-invalidated scalar cache and read the XCD's L2, where the producers' plain stores are); 1 / 2 =
+    // scalar loads with glc (correct, but every poll then sees a flag 5-17 us late: profiles/r03_decode_floor_experiments.txt).
+    // The scalar path keeps the poll out of the wave's vector-memory queue: vector loads return in order, so a wave that polls
+    // with vector loads cannot request its K/V panel or weights BEFORE the wait without the poll's data arriving behind them --
+    // with scalar polls EVERY wave requests early (-1.3 ... 1.9 % per generate).
     int poll;
     unsigned long long* stp;                                  // diagnostic: 5 ticks per stage (wait begin / end, drain begin / end, published)
     __device__ inline bool early_all() const { return poll != 0; }
