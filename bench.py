@@ -14,8 +14,8 @@ Objects on the line besides the contract's fields:
                   `traffic` = PMC bytes per launch from a separate rocprofv3 pass (file named in `traffic_source`).
   cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") on this host: `value` = recompute mode = the reference's
                   algorithm (no KV cache, decoder.py:97-103) on a bounded sample; `cached` = the same oracle with a KV cache.
-  fp32_parity_mode, b256, cfg4 (N=1 only, after the timed region; --no-extras skips them):
-                  the token-exact fp32 engine on the same workload; batch 256 (the north-star HBM target: cross-attention
+  fp32_parity_mode, sampled_decode, b256, cfg4 (N=1 only, after the timed region; --no-extras skips them):
+                  the token-exact fp32 engine on the same workload; the reference's default (sampled) decode; batch 256 (the north-star HBM target: cross-attention
                   >= 50 % of 8 TB/s); BASELINE configs[3] (ViT-Base 12L/768d + 6L decoder, B=256: encoder >= 40 % of the
                   bf16 MFMA peak).
 """
@@ -164,14 +164,14 @@ def make_step(dist_on, generate_no_eos, generate_default, imgs, max_len, eos, bo
     return step
 
 
-def timed(model, img, max_len, warm, steps):
+def timed(model, img, max_len, warm, steps, **gen_kw):
     import torch
     for _ in range(warm):
-        model.generate(img, max_len)
+        model.generate(img, max_len, **gen_kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = model.generate(img, max_len)
+        out = model.generate(img, max_len, **gen_kw)
     torch.cuda.synchronize()
     assert out.shape[1] == max_len
     return (time.perf_counter() - t0) / steps
@@ -183,9 +183,10 @@ def enc_flop(dims, B, N):
     return B * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
 
 
-def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encoder):
+def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encoder, sampled=False):
     """One extra configuration on this GPU: throughput, and on request the cross-attention launch (HIP events bound to the
-    dispatches of one generate) and the encoder span (marker events)."""
+    dispatches of one generate) and the encoder span (marker events).  sampled: the reference's DEFAULT decode (top-k 99,
+    temperature 0.3, one multinomial draw per step; ocr_model.py:47, decoder.py:104-108) instead of greedy."""
     import torch
     from texocr_amd import synth
     from texocr_amd.model import model_from_dims
@@ -194,7 +195,8 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
     m.load_state_dict(synth.synth_state_dict(dims, 0))
     g = torch.Generator(device=dev).manual_seed(4321)
     img = torch.rand((B, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
-    sec = timed(m, img, a.max_len, warm, steps)
+    m.eos_token = None if sampled else m.eos_token        # sampled rows may all hit eos early: keep the step at max_len positions
+    sec = timed(m, img, a.max_len, warm, steps, **({"temp": 0.3, "decode": "sample", "seed": 1} if sampled else {}))
     out = {"value": round(B / sec, 2), "unit": "images/sec", "ms_per_step": round(1000 * sec, 3), "batch": B, "dtype": dtype, "steps": steps}
     esz = 2 if dtype == "bf16" else 4
     eng = m._engine
@@ -396,6 +398,9 @@ def main():
             try:
                 result["fp32_parity_mode"] = side_measurement(dims, "fp32", a.batch, a, dev, 2, 5, False, False)
                 result["fp32_parity_mode"]["note"] = "same workload on the token-exact fp32 engine (tests/test_gpu_parity.py pins it to the reference)"
+                result["sampled_decode"] = side_measurement(dims, a.dtype, a.batch, a, dev, 2, 5, False, False, sampled=True)
+                result["sampled_decode"]["note"] = ("same workload with the reference's default decode (decode='sample': top-k 99, temperature 0.3, "
+                                                    "multinomial; eos test off so that all max_len positions run)")
                 result["b256"] = side_measurement(dims, a.dtype, 256, a, dev, 2, 4, True, False)
                 d4 = Dims(canvas=max(a.height, a.width), embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6)
                 result["cfg4"] = side_measurement(d4, a.dtype, 256, a, dev, 1, 3, True, True)
