@@ -1031,8 +1031,8 @@ struct Engine : EngineBase {
     // 256 steps; profiles/r02_persist_ab.txt, last table): width 256, every batch size up to 256 images in both modes -- bf16
     // 22.9 vs 29.1 ms for ONE image, 1998 vs 1522 images/s at batch 64, 2717 vs 2605 at 256; fp32 1094 vs 903 at batch 64.
     bool persist_usable(int B) const {
-        // sampling: the persistent kernel keeps one row per wave in the LDS of the GEMM tiles (8 waves x V floats)
-        if (sample_mode && (size_t)V * sizeof(float) * (PS_THREADS / 64) > 2 * ((size_t)DG_BM * D * sizeof(T) + 8192)) return false;
+        // sampling: the persistent kernel's sampler keeps a row in registers, 16 logits per lane (step.h: sample_row_regs)
+        if (sample_mode && V > 64 * SR_PER) return false;
         if (prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);

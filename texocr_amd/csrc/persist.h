@@ -488,11 +488,11 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 float best = -3.4e38f; int bi = 0x7fffffff;
                 if (a.sample) {
                     // the reference's default decode (decoder.py:104-108): top-k, softmax(/temp), one draw keyed by (seed; row, t) --
-                    // the same function and key as the launch path's sample_step_kernel, hence the same draw.  The wave's copy
-                    // of the row lives in the LDS the GEMM tiles use between the stage's barriers (V floats per wave).
-                    float* row_lds = reinterpret_cast<float*>(smem_all) + (size_t)(threadIdx.x >> 6) * a.V;
-                    bi = sample_row([&](int j) { return ldc_f32<true>(lg + j); }, row_lds, lo, a.V, lane, a.sample_topk, a.inv_temp,
-                                    a.seed, (unsigned)row, (unsigned)t);
+                    // the same function and key as the launch path's sample_step_kernel, hence the same draw.  The row lives in
+                    // registers (step.h: vocabularies up to 1024 entries; Engine::persist_usable sends larger ones to the launch path).
+                    auto ld = [&](int j) { return ldc_f32<true>(lg + j); };
+                    if constexpr (sizeof(T) == 2) bi = sample_row_regs(ld, lo, a.V, lane, a.sample_topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
+                    else bi = sample_row_regs_call(ld, lo, a.V, lane, a.sample_topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
                 } else {
                 if ((a.V & 3) == 0) {                          // four 16-byte pieces per lane in flight
                     const int n4 = a.V >> 2;
