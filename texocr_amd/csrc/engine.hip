@@ -1197,7 +1197,10 @@ struct Engine : EngineBase {
         const char* genv = getenv("TXO_GRAPH");
         const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
         const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
-        int want = 1;
+        // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
+        // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765); greedy only -- the sampler's
+        // counter RNG is keyed per range
+        int want = (D >= 512 && B >= 256 && !sample_mode && !prof && !prof_cross) ? 2 : 1;   // (profiling times whole-batch launches)
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
         set_lanes(want, s);
