@@ -1030,6 +1030,7 @@ struct Engine : EngineBase {
     // heads, or 768 with 12 heads in bf16, FFN factor 4).  Default: where it measured faster on MI355X (config.yml dims, 224x672,
     // 256 steps; profiles/r02_persist_ab.txt, last table): width 256, every batch size up to 256 images in both modes -- bf16
     // 22.9 vs 29.1 ms for ONE image, 1998 vs 1522 images/s at batch 64, 2717 vs 2605 at 256; fp32 1094 vs 903 at batch 64.
+    static constexpr int PERSIST_MAX_BF16_GREEDY = 128;
     bool persist_usable(int B) const {
         // sampling: the persistent kernel's sampler keeps a row in registers, 16 logits per lane (step.h: sample_row_regs)
         if (sample_mode && V > 64 * SR_PER) return false;
@@ -1040,6 +1041,10 @@ struct Engine : EngineBase {
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
         if (persist_fallbacks >= 2) return false;              // it gave up twice on this device (not all 256 workgroups co-resident?): stop paying the time-out
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
+        // bf16 greedy beyond 128 images: launches on TWO row ranges (two streams: one range's latency-bound projections beside the
+        // other's HBM-bound attention) are 4-7 % ahead of the persistent launch (144: 67.2 vs 69.6 ms, 160: 66.9 vs 71.8, 192: 75.1 vs 78.9, 256: 94.2
+        // vs 97.7; at 128 the persistent launch leads 53.7 vs 59.3); fp32 and sampled decode: persistent up to 256
+        if (sizeof(T) == 2 && !sample_mode && B > PERSIST_MAX_BF16_GREEDY) return false;
         return B <= 256;                                       // more rows per team than two 16-row tiles: not measured
     }
     template <int D_, int H_>
@@ -1200,7 +1205,9 @@ struct Engine : EngineBase {
         // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
         // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765); greedy only -- the sampler's
         // counter RNG is keyed per range
-        int want = (D >= 512 && B >= 256 && !sample_mode && !prof && !prof_cross) ? 2 : 1;   // (profiling times whole-batch launches)
+        // (also the narrow decoder's bf16 greedy decode beyond the persistent launch's range, see persist_usable)
+        int want = (sizeof(T) == 2 && !sample_mode && !prof && !prof_cross &&       // (profiling times whole-batch launches)
+                    ((D >= 512 && B >= 256) || (D < 512 && B > PERSIST_MAX_BF16_GREEDY))) ? 2 : 1;
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
         set_lanes(want, s);
