@@ -26,4 +26,6 @@ python3 probes/pmc_summary.py $O/pmc_bf16_b64 bf16 64 > $O/r03_pmc_bf16_b64.json
 python3 probes/pmc_summary.py $O/pmc_bf16_b256 bf16 256 > $O/r03_pmc_bf16_b256.json
 for d in b64 b256 cfg4 b64_launches b256_launches prefill; do f=$(find $O/prof_r03_$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r03_${d}_bf16_kernel_stats.csv; done
 python3 probes/sample_bench.py > $O/r03_sampled_decode.txt 2>&1
+# gpurun copies back at most 64 MiB: the raw traces and counter dumps are not needed once the summaries exist
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete
 ls -la $O | tail -24
