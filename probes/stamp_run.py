@@ -1,0 +1,14 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import torch
+from texocr_amd.config import Dims
+from texocr_amd import synth
+from texocr_amd.model import model_from_dims
+B = int(sys.argv[1]); out = sys.argv[2]
+d = Dims(canvas=672)
+m = model_from_dims(d, dtype="bf16", max_batch=B, max_tokens=589)
+m.load_state_dict(synth.synth_state_dict(d, 0))
+img = torch.rand((B, 3, 224, 672), device="cuda")
+m.generate(img, 256)
+os.environ["TXO_STAMPS"] = out
+m.generate(img, 256); torch.cuda.synchronize()

@@ -22,14 +22,22 @@ def _oracle():
     return cpu_ref
 
 
-def build(meta_or_dims, seed=None, dtype="fp32", max_batch=8, max_tokens=0):
+def build(meta_or_dims, seed=None, dtype="fp32", max_batch=8, max_tokens=0, latent=None, sd=None):
+    """latent: None = the engine's default choice of the cross-attention form; 0 / 1 = the projected K/V panels / the raw encoder
+    rows (csrc/lat_attn.h) on every decode with launches (TXO_LATENT, read once when the engine is created)."""
+    import os
     from texocr_amd.model import model_from_dims
     if isinstance(meta_or_dims, dict):
         d, seed = Dims(**meta_or_dims["dims"]), meta_or_dims["weight_seed"]
     else:
         d = meta_or_dims
-    sd = synth.synth_state_dict(d, seed)
-    m = model_from_dims(d, dtype=dtype, max_batch=max_batch, max_tokens=max_tokens)
+    sd = sd if sd is not None else synth.synth_state_dict(d, seed)
+    if latent is not None:
+        os.environ["TXO_LATENT"] = str(int(latent))
+    try:
+        m = model_from_dims(d, dtype=dtype, max_batch=max_batch, max_tokens=max_tokens)
+    finally:
+        os.environ.pop("TXO_LATENT", None)
     m.load_state_dict(sd)
     return d, sd, m
 
@@ -740,7 +748,9 @@ def test_large_ragged_batch_rows_independent():
     if bool((toks.cpu() == ref_t).all()):
         assert float((logits.cpu() - ref_l).abs().max()) < 1e-3
     for dtype in ("fp32", "bf16"):
-        _, _, mm = build(d, seed=21, dtype=dtype, max_batch=130)
+        # (bf16 perf mode: beyond 128 rows the launches default to the latent form of the cross attention, whose low bits differ
+        # from the K/V form's -- the property is asserted per form; the fp32 parity mode has ONE form at every batch size)
+        _, _, mm = build(d, seed=21, dtype=dtype, max_batch=130, latent=0)
         mm.eos_token = None
         big_t, big_l = mm.generate(img.cuda(), 12, return_logits=True)
         small_t, small_l = mm.generate(img[:64].cuda(), 12, return_logits=True)
@@ -841,7 +851,7 @@ def test_persistent_decode_bit_identical_to_launches(dtype, B):
     size (1 row in one team ... 13 rows in each of 8 teams with a ragged last one ... 25 rows per team: two 16-row
     tiles per GEMM stage and four rounds of attention pairs)."""
     d = Dims(canvas=224)
-    d, sd, m = build(d, seed=3, dtype=dtype, max_batch=B)
+    d, sd, m = build(d, seed=3, dtype=dtype, max_batch=B, latent=0)     # (beyond 128 rows bf16 launches default to the latent form)
     g = torch.Generator(device="cuda").manual_seed(77 + B)
     img = torch.rand((B, 3, 64, 224), generator=g, device="cuda")
     (tp, lp), (tl, ll) = _both_paths(m, img, 40, return_logits=True)
@@ -1042,14 +1052,14 @@ def test_persistent_eos_break_when_teams_drift_apart(stagger_us, monkeypatch):
         monkeypatch.setenv("TXO_PERSIST", "0")
         tl = m.generate(img, 256)
         monkeypatch.setenv("TXO_PERSIST", "1"); monkeypatch.setenv("TXO_PS_STAGGER_US", stagger_us)
+        monkeypatch.setenv("TXO_DEBUG_POISON", "1")                   # ops.py pre-fills the token block with -7: an undecoded column would show
         for _ in range(3):
-            fill = torch.full((20, 256), -7, dtype=torch.int64, device="cuda")      # poison: an undecoded column would show
-            del fill
             tp = m.generate(img, 256)
+            assert int(tp.min()) >= 0
             assert m._engine.query(0) == 1 and m._engine.query(1) == 0
             assert tp.shape == (20, last + 1), (eos, last, row, tuple(tp.shape))
             assert torch.equal(tp, tl), (eos, last, row)
-        monkeypatch.delenv("TXO_PS_STAGGER_US")
+        monkeypatch.delenv("TXO_PS_STAGGER_US"); monkeypatch.delenv("TXO_DEBUG_POISON")
         assert np.array_equal(tp.cpu().numpy(), free[:, :last + 1])
     ref = cpu_ref.generate_cached(cpu_ref.to_torch_sd(sd), img.cpu(), d.bos, cands[0][0], 256)
     m.eos_token = cands[0][0]
@@ -1220,3 +1230,171 @@ def test_torch_free_c_program_on_the_c_abi(tmp_path):
     r = subprocess.run([exe, blob], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "match the reference" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# round 4: the cross attention in latent form (csrc/lat_attn.h), and the bf16 mode pinned to the reference at the
+# benchmark's own shape over every position
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", ["cfg1", "tiny64", "width672", "vitbase"])
+def test_latent_cross_attention_matches_kv_form_fp32(shape):
+    """energy_h[n] = q_h . (Wk_h enc[n]) * 0.125 = (0.125 Wk_h^T q_h) . enc[n] and out_h = Wv_h (sum_n p_h[n] enc[n])
+    (reference model/attention.py:124-127,148,166,172-173,248): the latent form re-associates the reference's sums, so in the
+    fp32 parity mode its logits must equal the K/V form's to rounding (asserted < 1e-5; measured 3e-6) and the greedy tokens must
+    be the same, at 197 keys, at one head of a 64-wide model, at the benchmark's 589 keys, and (bf16 storage only exists there:
+    the fp32 tile does not fit 768-wide rows) for a ViT-Base-wide decoder against its own K/V form within the bf16 bound."""
+    dtype, bound = "fp32", 1e-5
+    if shape == "cfg1":
+        d, B, H, W, T = Dims(canvas=224), 4, 224, 224, 48
+    elif shape == "tiny64":
+        d, B, H, W, T = Dims(canvas=64, embed_dim=64, enc_heads=1, enc_layers=1, dec_heads=1, dec_layers=1, vocab=32, max_len=8,
+                             bos=30, eos=29, pad=31), 3, 64, 64, 8
+    elif shape == "width672":
+        d, B, H, W, T = Dims(canvas=672), 5, 224, 672, 24
+    else:
+        d, B, H, W, T = Dims(canvas=224, embed_dim=768, enc_heads=12, enc_layers=2, dec_heads=12, dec_layers=2), 4, 224, 224, 16
+        dtype, bound = "bf16", 0.08
+    img = torch.from_numpy(synth.synth_images(B, 3, H, W, seed=7)).cuda()
+    outs = []
+    for latent in (0, 1):
+        _, _, m = build(d, seed=2, dtype=dtype, max_batch=B, latent=latent)
+        m.eos_token = None
+        toks, logits = m.generate(img, T, return_logits=True)
+        assert m._engine.query(0) == (0 if latent else m._engine.query(0))       # forced latent form decodes with launches
+        outs.append((toks.cpu(), logits.cpu()))
+        del m
+    (t0, l0), (t1, l1) = outs
+    first = float((l0[:, 0] - l1[:, 0]).abs().max())
+    print(f"latent vs K/V form, {shape} {dtype}: max |dlogit| at position 0 {first:.3e}, token agreement {float((t0 == t1).float().mean()):.4f}")
+    assert first < bound
+    if dtype == "fp32":
+        assert torch.equal(t0, t1)
+        assert float((l0 - l1).abs().max()) < bound
+
+
+def test_latent_form_fp32_meets_the_reference_fixture_at_the_benchmark_shape():
+    """The latent form against the REFERENCE (not against the build's other form): 3x224x672, 256 greedy steps captured from
+    the reference, decoded as rows 41 and 6 of a 64-image batch on the fp32 engine with the latent tile: every token exact
+    (fixture margin >= 1e-4), logits over the reference's top-5 of every step within 1e-3."""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    d, sd, m = build(meta, max_batch=64, max_tokens=589, latent=1)
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand((64, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[41], img[6] = fix[0], fix[1]
+    toks, logits = m.generate(img, 256, return_logits=True)
+    assert m._engine.query(0) == 0
+    assert np.array_equal(toks[[41, 6]].cpu().numpy(), g["tokens"])
+    v = torch.gather(logits[[41, 6]].cpu(), 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    err = float((v - torch.from_numpy(g["top5_vals"])).abs().max())
+    print(f"cfg2 t256, fp32 latent form: max |dlogit| over the reference's top-5 of all 2x256 steps {err:.2e}")
+    assert err < 1e-3
+
+
+def _teacher_forced_stepwise(m, d, img, ref_tokens, monkeypatch):
+    """decoder.net() as single-position steps (TXO_NET_STEPWISE=1): the reference's tokens fed through the DECODE kernels of the
+    launch path (dec_gemm / dec_attn or lat_attn), every position's logits"""
+    toks = torch.from_numpy(ref_tokens.astype(np.int64)).cuda()
+    prefix = torch.cat([torch.full((toks.shape[0], 1), d.bos, dtype=torch.long, device="cuda"), toks[:, :-1]], 1)
+    monkeypatch.setenv("TXO_NET_STEPWISE", "1")
+    try:
+        return m.decoder.net(prefix, enc=m.encoder(img)).cpu(), toks.cpu()
+    finally:
+        monkeypatch.delenv("TXO_NET_STEPWISE")
+
+
+@pytest.mark.parametrize("form", ["kv", "latent"])
+def test_bf16_benchmark_shape_vs_reference_every_position(form, monkeypatch):
+    """The mode the headline number is quoted in against the reference at the benchmark's OWN shape: fixture
+    cfg2_b2_224x672_t256 (3x224x672 = 589 keys, self history beyond 128 positions), the reference's 2 x 256 tokens teacher-forced
+    through the bf16 engine's decode kernels, both forms of the cross attention: logits over the reference's top-5 of every
+    position and top-1 agreement, bounds at 1.5x the measurement."""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    d, sd, m = build(meta, dtype="bf16", max_batch=2, max_tokens=589, latent=(1 if form == "latent" else 0))
+    img = images(meta).cuda()
+    tf, toks = _teacher_forced_stepwise(m, d, img, g["tokens"], monkeypatch)
+    got = torch.gather(tf, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    err = float((got - torch.from_numpy(g["top5_vals"])).abs().max())
+    agree = float((tf.argmax(-1) == toks).float().mean())
+    flips = (tf.argmax(-1) != toks).numpy()
+    worst = float(g["margin"][flips].max()) if flips.any() else 0.0
+    print(f"cfg2 t256 bf16 ({form} form) vs reference, teacher-forced 2x256: max |dlogit| over the reference's top-5 {err:.4f}, "
+          f"top-1 agreement {agree:.4f}, largest reference margin among the flipped positions {worst:.4f}")
+    assert err < 0.035, err                                    # 1.5x the measurement (r04: K/V form 0.0228 / 0.9941, latent form 0.0220 / 0.9902)
+    assert agree > 0.985, agree
+    assert worst < 2 * 0.035                                   # a flip needs a margin thinner than twice the logit error (measured: <= 0.0082)
+
+
+@pytest.mark.parametrize("path", ["persistent", "launches"])
+def test_bf16_benchmark_shape_free_running_inside_batch_64(path, monkeypatch):
+    """... and free-running on both decode paths (the persistent launch cannot be teacher-forced): the fixture images as rows 41 and
+    6 of a 64-image bf16 batch follow the reference's tokens until the first position whose reference margin is thinner than the
+    bf16 logit error, and the logits on that common prefix stay within the bound; both paths return the same tokens."""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    d, sd, m = build(meta, dtype="bf16", max_batch=64, max_tokens=589, latent=0)
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand((64, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[41], img[6] = fix[0], fix[1]
+    monkeypatch.setenv("TXO_PERSIST", "1" if path == "persistent" else "0")
+    toks, logits = m.generate(img, 256, return_logits=True)
+    assert m._engine.query(0) == (1 if path == "persistent" else 0) and m._engine.query(1) == 0
+    got_t, got_l = toks[[41, 6]].cpu().numpy(), logits[[41, 6]].cpu()
+    worst_err, shortest = 0.0, 256
+    for r in range(2):
+        diff = np.nonzero(got_t[r] != g["tokens"][r])[0]
+        k = int(diff[0]) if diff.size else 255             # logits of position k were still computed from the reference's prefix
+        v = torch.gather(got_l[r, :k + 1], 1, torch.from_numpy(g["top5_ids"][r, :k + 1].astype(np.int64)))
+        worst_err = max(worst_err, float((v - torch.from_numpy(g["top5_vals"][r, :k + 1])).abs().max()))
+        shortest = min(shortest, k)
+        if diff.size:
+            assert float(g["margin"][r, k]) < 2 * 0.035, (r, k, float(g["margin"][r, k]))
+    print(f"cfg2 t256 bf16 free-running ({path}) inside batch 64: common prefix >= {shortest} positions, max |dlogit| over the top-5 on it {worst_err:.4f}")
+    assert worst_err < 0.035 and shortest >= 32                # measured 0.0208 on a common prefix of 53 positions
+    monkeypatch.setenv("TXO_PERSIST", "0" if path == "persistent" else "1")
+    assert torch.equal(m.generate(img, 256), toks)            # the other path: same tokens
+
+
+@pytest.mark.parametrize("form", ["kv", "latent"])
+def test_bf16_cfg4_vs_reference_64_positions(form, monkeypatch):
+    """ViT-Base + 6L decoder in bf16 against the reference's 2 x 64 tokens (fixture cfg4_b2_224x672_t64), teacher-forced through
+    the decode kernels of the launch path, both forms (the 768-wide latent tile: 4 waves, one tile of encoder rows per wave)."""
+    meta, g = load_golden("cfg4_b2_224x672_t64")
+    d, sd, m = build(meta, dtype="bf16", max_batch=2, max_tokens=589, latent=(1 if form == "latent" else 0))
+    img = images(meta).cuda()
+    tf, toks = _teacher_forced_stepwise(m, d, img, g["tokens"], monkeypatch)
+    got = torch.gather(tf, 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
+    err = float((got - torch.from_numpy(g["top5_vals"])).abs().max())
+    agree = float((tf.argmax(-1) == toks).float().mean())
+    print(f"cfg4 t64 bf16 ({form} form) vs reference, teacher-forced 2x64: max |dlogit| over the reference's top-5 {err:.4f}, top-1 agreement {agree:.4f}")
+    assert err < 0.039, err                                    # 1.5x the measurement (r04: 0.0258 / 0.0251, top-1 0.9844 both forms)
+    assert agree > 0.976, agree
+
+
+def test_two_row_ranges_bit_identical_to_one(monkeypatch):
+    """The default decode beyond 128 images in bf16 (two row ranges on two streams, latent cross attention) against ONE range
+    (TXO_LANES=1): rows never interact, so the tokens must be identical -- at batch 256, the benchmark's image size."""
+    d = Dims(canvas=672)
+    d, sd, m = build(d, seed=0, dtype="bf16", max_batch=256, max_tokens=589)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    img = torch.rand((256, 3, 224, 672), generator=gen, device="cuda")
+    t2 = m.generate(img, 96)
+    assert m._engine.query(0) == 0
+    monkeypatch.setenv("TXO_LANES", "1")
+    t1 = m.generate(img, 96)
+    assert torch.equal(t1, t2)
+
+
+def test_fp32_fixture_on_two_row_ranges(monkeypatch):
+    """the fp32 reference-fixture run of the benchmark's shape (rows 41 and 6 of 64) with the batch decoded as TWO row ranges on
+    two streams (TXO_LANES=2): tokens exact, logits within 1e-3"""
+    meta, g = load_golden("cfg2_b2_224x672_t256")
+    d, sd, m = build(meta, max_batch=64, max_tokens=589)
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    img = torch.rand((64, 3, 224, 672), generator=gen, device="cuda")
+    fix = images(meta).cuda()
+    img[41], img[6] = fix[0], fix[1]
+    monkeypatch.setenv("TXO_LANES", "2")
+    toks = m.generate(img, 256)
+    assert m._engine.query(0) == 0
+    assert np.array_equal(toks[[41, 6]].cpu().numpy(), g["tokens"])

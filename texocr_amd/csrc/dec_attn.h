@@ -196,7 +196,7 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
     // is read with the default policy (measured: self-attention launch 6.2 -> 5.4 us)
     // the self-attention cache is read with plain loads also in the persistent kernel: a row is final once its position's
     // hand-off has passed, and no CU reads it earlier (clamps below), so no L1 can hold an older copy of its lines
-    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF) return ld16(p); else return ld16_stream(p); };
+    auto ld_kv = [](const T* p) -> u32x4 { if constexpr (MODE == ATT_SELF && !(COH && TXO_PS_W_NT)) return ld16(p); else return ld16_stream(p); };
     int clamp_row = Lm1;
     auto issue_k = [&](int base) {
 #pragma unroll

@@ -78,6 +78,13 @@ struct NoPf { __device__ inline void operator()() const {} };
 // Weight fragments of one tile (one wave's share, K fixed at compile time: KW 64-byte chunks per wave) can be requested one
 // stage ahead by the persistent kernel (dec_gemm_prefetch) into ONE small register buffer shared by all stages:
 // layout w0[0..KW) then (32-column tiles) w1[0..KW).
+// experiment build (-DTXO_PS_W_NT=1): inside the persistent kernel the decoder weights (18 MB per position and XCD, far beyond its 4 MiB
+// L2) are requested non-temporally, so that the stream does not push the latent cross attention's encoder rows (2.4 MB per XCD,
+// re-read by every layer) out of that L2
+#ifndef TXO_PS_W_NT
+#define TXO_PS_W_NT 0
+#endif
+template <bool COH> __device__ inline u32x4 ld16_w(const void* p) { if constexpr (COH && TXO_PS_W_NT) return ld16_stream(p); else return ld16(p); }
 constexpr int wfrag_regs(int KW, int BN) { return KW * (BN == 32 ? 2 : 1); }
 constexpr int WBUF_REGS = 8;
 struct WBuf { u32x4 r[WBUF_REGS]; };
@@ -216,7 +223,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch) {
             const int kc = wave + 4 * (g0 + c);
-            fw0[c] = ld16(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16(w1 + kc * KCH);
+            fw0[c] = ld16_w<COH>(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16_w<COH>(w1 + kc * KCH);
         }
     };
     auto load_a_global = [&](int g0) {

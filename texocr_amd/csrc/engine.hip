@@ -22,6 +22,7 @@
 #include "enc_attn.h"
 #include "gemm_big.h"
 #include "gemm_pp.h"
+#include "lat_attn.h"
 #include "persist.h"
 #include "prefill.h"
 #include "rows.h"
@@ -102,7 +103,8 @@ struct Engine : EngineBase {
     // ----- device weights -----
     std::vector<void*> allocs;
     struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr;
-                   T* wo16 = nullptr; float* bo16 = nullptr; };   // decoder: second copy interleaved by 16 (prefill: the large-GEMM epilogues)
+                   T* wo16 = nullptr; float* bo16 = nullptr;    // decoder: second copy interleaved by 16 (prefill: the large-GEMM epilogues)
+                   T* wkT = nullptr; T* wv = nullptr; };        // decoder cross attention, latent form (lat_attn.h): Wk per head transposed [heads][D][64], Wv [inner][D]
     struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr;
                   T* w1_16 = nullptr; float* b1_16 = nullptr; };   // decoder, wide rows: second copy interleaved by 16 (large-batch FFN-in)
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
@@ -134,11 +136,20 @@ struct Engine : EngineBase {
         hipStream_t stream = nullptr;      // lane 0 runs on the caller's stream
         hipStream_t own = nullptr;         // engine-owned stream for lanes > 0
         hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        int gb0 = -1, gnb = -1, gN = -1, geos = -2, gsB = -1, gsImg = -1;   // what the captured graph was built for (the cache strides sB / sImg are baked into its launches)
+        int gb0 = -1, gnb = -1, gN = -1, geos = -2, gsB = -1, gsImg = -1, glat = -1;   // what the captured graph was built for (the cache strides sB / sImg are baked into its launches)
     };
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
+    // experiment knobs are read ONCE per engine (never on a launch path)
+    bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
+    // cross attention in latent form (lat_attn.h): scores / values against the raw encoder rows instead of projected K/V panels.
+    // latent_ok: the tile exists for this engine's width / storage type.  lat_mode (TXO_LATENT, read once): 1 = every decode runs with
+    // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
+    bool latent_ok = false, use_latent = false, la_attr_set = false;
+    int lat_mode = getenv("TXO_LATENT") ? atoi(getenv("TXO_LATENT")) : -1;
+    int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0, lat_stamp_mode = getenv("TXO_LAT_STAMP_MODE") ? atoi(getenv("TXO_LAT_STAMP_MODE")) : 0;
+    bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
@@ -272,6 +283,13 @@ struct Engine : EngineBase {
             if (int r = upload_T(&w->wq, q->data)) return r;
             kv_concat->insert(kv_concat->end(), k->data.begin(), k->data.end());
             kv_concat->insert(kv_concat->end(), v->data.begin(), v->data.end());
+            // latent form: q'_h = Wk_h^T q_h reads COLUMNS of Wk_h -> stored transposed per head, [heads][D][64]
+            std::vector<float> kT((size_t)inner * D);
+            for (int h = 0; h < inner / DH; ++h)
+                for (int d = 0; d < D; ++d)
+                    for (int j = 0; j < DH; ++j) kT[((size_t)h * D + d) * DH + j] = k->data[((size_t)h * DH + j) * D + d];
+            if (int r = upload_T(&w->wkT, kT)) return r;
+            if (int r = upload_T(&w->wv, v->data)) return r;
         } else {
             std::vector<float> cat(q->data);
             cat.insert(cat.end(), k->data.begin(), k->data.end());
@@ -373,6 +391,8 @@ struct Engine : EngineBase {
             for (auto& kv : host) bytes += kv.second.data.size() * sizeof(float) + 512;
             // + the decoder's second (16-interleaved) copies of the gated projections for the prefill
             bytes += (size_t)cfg.dec_layers * ((size_t)2 * 2 * D * Id + (size_t)2 * Fd * D + 4 * D + 2 * Fd + 4096) * sizeof(float);
+            // + the latent form's copies of the cross-attention Wk (transposed per head) and Wv
+            bytes += (size_t)cfg.dec_layers * ((size_t)2 * D * Id + 1024) * sizeof(float);
             if (int r = arena_begin(bytes + (1u << 20))) return r;
         }
         const int npos = 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
@@ -466,6 +486,10 @@ struct Engine : EngineBase {
         D = c.embed_dim; Ie = c.enc_heads * DH; Id = c.dec_heads * DH; Fe = c.enc_exp * D; Fd = c.dec_exp * D;
         V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
         hybrid = c.embed == TXO_EMBED_HYBRID;
+        {
+            const bool exists = (D == 64 && la_supported<T, 64>()) || (D == 256 && la_supported<T, 256>()) || (D == 768 && la_supported<T, 768>());
+            latent_ok = exists;
+        }
         Nmax = c.max_tokens > 0 ? c.max_tokens : 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
         const size_t M = (size_t)Bmax * Nmax;
         const int Imax = Ie > Id ? Ie : Id, Fmax = Fe > Fd ? Fe : Fd;
@@ -542,7 +566,7 @@ struct Engine : EngineBase {
         same_pad(H, k, stride, &OH, &pt); same_pad(W, k, stride, &OW, &pl);
         // a 1x1 stride-1 convolution on NHWC activations IS a plain row-major GEMM: [B*H*W][C] x [OC][C]^T -> the 256x256 LDS-DMA
         // kernel where the shape fits it (bf16: the bottlenecks' expanding convolutions, 256 / 512 / 1024 output channels)
-        if (k == 1 && stride == 1 && !getenv("TXO_CONV1X1_OLD")) { gemm_plain(s, in, w, B * H * W, OC, C, EpiStore<T>{out, OC, nullptr}); return; }
+        if (k == 1 && stride == 1 && !conv1x1_old) { gemm_plain(s, in, w, B * H * W, OC, C, EpiStore<T>{out, OC, nullptr}); return; }
         LoadConv<T> ld{in, H, W, C, stride, pt, pl, FastDiv(OH * OW), FastDiv(OW), FastDiv(C), FastDiv(k)};
         launch_gemm_big<T>(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<T>{out, OC, nullptr});
     }
@@ -645,26 +669,36 @@ struct Engine : EngineBase {
         return 0;
     }
 
-    int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) override {
+    // project_kv = false: generate() decides the form of the cross attention once it knows its decode path
+    int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) override { return begin_session(enc, B, N, eos, s, true); }
+    int begin_session(const float* enc, int B, int N, int eos, hipStream_t s, bool project_kv) {
         if (!ready) return fail(TXO_E_STATE, "weights not finalized");
         if (B < 1 || B > Bmax) return fail(TXO_E_INVALID, "batch exceeds engine max_batch");
         if (N < 1 || N > Nmax) return fail(TXO_E_INVALID, "token count exceeds engine max_tokens");
         const int M = B * N;
-        const T* a_enc;
-        if constexpr (sizeof(T) == 4) a_enc = enc;
-        else {
+        {   // the session's copy of the encoder rows in the storage type: A operand of the K/V projection; in the latent form what
+            // every cross-attention tile of every layer reads (the caller's buffer is not referenced after this call)
             const size_t n4 = (size_t)M * D / 4;
             hipLaunchKernelGGL((cast_rows_kernel<T>), dim3((n4 + 255) / 256), dim3(256), 0, s, enc, enc_t, n4);
-            a_enc = enc_t;
         }
-        // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D]
-        gemm_plain(s, a_enc, wckv, M, cfg.dec_layers * 2 * Id, D,
-                           EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, N});
         sB = B; sN = N; sImg = B; session = true;
+        ckv_valid = false;
+        // a session opened through the C entry point steps with launches: latent form only when forced
+        use_latent = latent_ok && lat_mode == 1;
+        if (!use_latent && project_kv) ensure_ckv(s);
         set_lanes(1, s);
         reset_lanes(s, eos);
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+
+    // K/V of every decoder layer's cross attention in one GEMM: W = [Ld][k|v][Id][D] (attention.py:125-126).  The K/V form's decode
+    // steps and the multi-position prefill read these panels; a latent-form session projects them only if a prefill asks.
+    void ensure_ckv(hipStream_t s) {
+        if (ckv_valid) return;
+        const int M = sImg * sN;
+        gemm_plain(s, enc_t, wckv, M, cfg.dec_layers * 2 * Id, D, EpiHeads<T>{ckv, (size_t)M * Id, Id, cfg.dec_heads, sN});
+        ckv_valid = true;
     }
 
     // split the batch into n contiguous row ranges (multiples of 16 rows where possible)
@@ -734,7 +768,7 @@ struct Engine : EngineBase {
     bool launch_dec_gemm_wide(hipStream_t s, DecGemmArgs<T> a) {
         if constexpr (sizeof(T) != 2) { (void)s; (void)a; return false; }
         else {
-            if (a.rows < 128 || D < 512 || getenv("TXO_DEC_WIDE_OFF")) return false;
+            if (a.rows < 128 || D < 512 || dec_wide_off) return false;
             constexpr int KCH = Elem<T>::KCHUNK;
             const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
             a.stamps = nullptr;
@@ -798,6 +832,50 @@ struct Engine : EngineBase {
         if (timed) ev_cross.push_back({e0, e1});
     }
 
+    // Where the latent form measured faster on MI355X with launches (config.yml dims, 224x672, bf16): from 129 rows on (batch 256:
+    // cross-attention launch 49 -> 32 us, 2700 -> 3290 images/s).  Up to 128 rows the persistent kernel decodes (K/V form: at one
+    // (row, head group) tile per CU the latent tile moves 493 KB per CU against 300 KB and is slower, 19 vs 16 us per launch at batch
+    // 64); wide decoders (768: the in-tile projections' weights are 3.4 MB per row) and the fp32 parity mode keep the K/V form.
+    bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY && !sample_mode; }
+    // heads per latent tile: the smallest group that leaves at most one tile per CU for `rows` rows (fewer tiles = fewer
+    // re-reads of an image's encoder rows; more tiles = more CUs pulling).  A head's bits do not depend on it.
+    int latent_group(int rows, int slots) const {
+        const int H = cfg.dec_heads;
+        if (lat_g_env > 0) return std::min(std::min(H, LA_GMAX), lat_g_env);
+        for (int g = 2; g < std::min(H, LA_GMAX); g *= 2)
+            if (rows * ((H + g - 1) / g) <= slots) return g;
+        return std::min(H, LA_GMAX);
+    }
+    // cross attention of layer l in latent form (lat_attn.h): LN sandwich + q + q' + scores / values against the raw encoder rows + Wv
+    void launch_lat_attn(hipStream_t s, int li, int l, int kv_div) {
+        const Lane& ln = lanes[li];
+        const size_t r0 = ln.b0;
+        LatAttnArgs<T> a{};
+        a.y = dy + r0 * D; a.x_out = dx + r0 * D; a.gamma = dec_g; a.beta = dec_b;
+        a.heads = cfg.dec_heads; a.G = latent_group(sB, 256); a.ngrp = (a.heads + a.G - 1) / a.G; a.len = sN;
+        a.Wq = dec_cross[l].wq; a.WkT = dec_cross[l].wkT; a.Wv = dec_cross[l].wv;
+        a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D; a.out = dao + r0 * Id; a.kv_div = kv_div;
+        a.stamps = (((ln.nb + 7) / 8) * 8 * a.ngrp <= STAMP_BLOCKS) ? next_stamp("attn cross (latent)") : nullptr; a.stamp_mode = lat_stamp_mode;
+        a.rows = ln.nb;
+        const dim3 grid(((ln.nb + 7) / 8) * 8 * a.ngrp);          // XCD-aware tile order (lat_attn_kernel)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());
+        if (timed) { e0 = pool.next(); e1 = pool.next(); }
+#define TXO_LA(D_)                                                                                                           \
+        do {                                                                                                                 \
+            if constexpr (la_supported<T, D_>()) {                                                                           \
+                auto kern = lat_attn_kernel<T, D_>;                                                                          \
+                const size_t lds = la_lds_bytes<T, D_>();                                                                    \
+                if (!la_attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); la_attr_set = true; } \
+                if (timed) hipExtLaunchKernelGGL(kern, grid, dim3(la_waves<D_>() * 64), lds, s, e0, e1, 0, a);             \
+                else hipLaunchKernelGGL(kern, grid, dim3(la_waves<D_>() * 64), lds, s, a);                                  \
+            }                                                                                                                \
+        } while (0)
+        if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
+#undef TXO_LA
+        if (timed) ev_cross.push_back({e0, e1});
+    }
+
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
     // host_t: the decode position when the caller knows it (every eager loop does); -1 makes the kernels read the
     // device-side counter instead, which is what lets ONE captured graph serve every step
@@ -842,11 +920,14 @@ struct Engine : EngineBase {
                 if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
                 dbg(s, "self out", l);
             }
-            {   // cross attention over the cached encoder projections (LN sandwich + q projection fused in)
+            {   // cross attention (LN sandwich + q projection fused in): against the raw encoder rows (latent form) or over the cached projections
+                if (use_latent) launch_lat_attn(s, li, l, bm ? bm->k : 1);
+                else {
                 AttnOpt o; o.cross = true; o.W = dec_cross[l].wq; o.K = ckv + (size_t)(2 * l) * cross_stride;
                 o.V = ckv + (size_t)(2 * l + 1) * cross_stride; o.lmax = N; o.len = N; o.x_out = lx;
                 if (bm) o.kv_div = bm->k;
                 launch_dec_attn(s, li, o);
+                }
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
                 g.resid = lx; g.y_out = ly;
@@ -921,7 +1002,7 @@ struct Engine : EngineBase {
     // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
     int lane_graph(int li, int eos) {
         Lane& ln = lanes[li];
-        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg) return 0;
+        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg && ln.glat == (int)use_latent) return 0;
         if (ln.exec) { (void)hipGraphExecDestroy(ln.exec); ln.exec = nullptr; }
         if (ln.graph) { (void)hipGraphDestroy(ln.graph); ln.graph = nullptr; }
         hipStream_t cs = cap_stream;
@@ -931,7 +1012,7 @@ struct Engine : EngineBase {
         if (r) return r;
         if (e != hipSuccess) return fail(TXO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         HIP_TRY(hipGraphInstantiate(&ln.exec, ln.graph, nullptr, nullptr, 0));
-        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg;
+        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg; ln.glat = (int)use_latent;
         return 0;
     }
 
@@ -974,6 +1055,7 @@ struct Engine : EngineBase {
         const size_t cap = (size_t)Bmax * Nmax;               // rows of the encoder workspace
         if ((size_t)t > cap) return fail(TXO_E_INVALID, "prefill: one prefix does not fit the engine's workspace (max_batch * max_tokens rows)");
         const int B = sB, N = sN, heads = cfg.dec_heads;
+        ensure_ckv(s);
         const int bc = (int)std::min<size_t>(B, cap / t);     // images per chunk
         const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)sImg * N * Id;
         T* qbuf = reinterpret_cast<T*>(eqkv);
@@ -1038,6 +1120,7 @@ struct Engine : EngineBase {
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
+        if (latent_ok && lat_mode == 1) return false;           // latent form forced: the persistent kernel reads projected K/V panels
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
         if (persist_fallbacks >= 2) return false;              // it gave up twice on this device (not all 256 workgroups co-resident?): stop paying the time-out
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
@@ -1050,7 +1133,7 @@ struct Engine : EngineBase {
     template <int D_, int H_>
     int launch_persist(const PersistArgs<T>& pa, hipStream_t s) {
         const size_t lds = persist_lds_bytes<T, D_, H_>();
-        auto kern = decode_persist_kernel<T, D_, H_>;
+        auto kern = sample_mode ? decode_persist_kernel<T, D_, H_, true> : decode_persist_kernel<T, D_, H_, false>;
         // per DEVICE, not per process (one process may drive several GPUs through several engines): set on every launch, it is cheap
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             (void)hipGetLastError();
@@ -1177,10 +1260,12 @@ struct Engine : EngineBase {
             if (int r = encode(img, B, C, H, W, eenc, s)) return r;
             enc = eenc; N = 1 + (H / 16) * (W / 16);
         }
-        if (int r = decode_begin(enc, B, N, eos, s)) return r;   // eos also decides whether the BOS column counts
+        if (int r = begin_session(enc, B, N, eos, s, false)) return r;   // eos also decides whether the BOS column counts
         last_persist = false;
         if (persist_usable(B)) {
             int steps = 0;
+            use_latent = false;
+            ensure_ckv(s);
             const int pr = generate_persist(B, N, n_pos, max_len, eos, tokens_out, logits_out, &steps, s);
             if (pr == 0) {
                 last_persist = true;
@@ -1199,6 +1284,8 @@ struct Engine : EngineBase {
         // single-stream launches (57.1 vs 58.0 / 58.2 ms) -- so both stay opt-in: TXO_GRAPH=1, TXO_LANES=n.
         // graph replay by default only for very small batches (B <= 4: there the host's enqueue rate bounds the step --
         // 34.2 vs 37.2 ms per generate at B = 1 -- from B = 8 on it is equal); TXO_GRAPH=1 / 0 forces it on / off
+        use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
+        if (!use_latent) ensure_ckv(s);
         const char* genv = getenv("TXO_GRAPH");
         const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
         const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
@@ -1322,7 +1409,9 @@ struct Engine : EngineBase {
             if (int r = encode(img, B, C, H, W, eenc, s)) return r;
             enc = eenc; N = 1 + (H / 16) * (W / 16);
         }
-        if (int r = decode_begin(enc, B, N, eos, s)) return r;       // cross K/V of the B images
+        if (int r = begin_session(enc, B, N, eos, s, false)) return r;
+        use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(rows)));
+        if (!use_latent) ensure_ckv(s);                               // cross K/V of the B images
         sB = rows; sImg = B;                                          // decode rows are (image, beam) slots
         set_lanes(1, s);
         const int n = std::max(rows, Tmax);

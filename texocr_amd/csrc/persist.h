@@ -218,7 +218,9 @@ constexpr size_t persist_lds_bytes() {
            4 * (size_t)D_ * sizeof(float);                    // LayerNorm gamma / beta of the stack and of the final norm (dec_gemm.h: ln_lds)
 }
 
-template <typename T, int D_, int HEADS_>
+// SAMPLE: the position's last stage is the reference's sampler (step.h) instead of the arg-max.  Two instantiations: the greedy
+// kernel carries no sampler code (the sampler inlined into ONE kernel behind a run-time flag cost the greedy decode 40 VGPRs).
+template <typename T, int D_, int HEADS_, bool SAMPLE>
 __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<T> a) {
     constexpr int D = D_, HEADS = HEADS_, ID = HEADS * DH, F = 4 * D;
     constexpr size_t GLDS = persist_group_lds<T, D_, HEADS_>();
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 const float* lg = a.dlogits + (size_t)row * a.V;
                 float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
                 float best = -3.4e38f; int bi = 0x7fffffff;
-                if (a.sample) {
+                if constexpr (SAMPLE) {
                     // the reference's default decode (decoder.py:104-108): top-k, softmax(/temp), one draw keyed by (seed; row, t) --
                     // the same function and key as the launch path's sample_step_kernel, hence the same draw.  The row lives in
                     // registers (step.h: vocabularies up to 1024 entries; Engine::persist_usable sends larger ones to the launch path).

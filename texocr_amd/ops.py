@@ -19,6 +19,7 @@ There is no CPU implementation: calling an operator on CPU tensors raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Dict, Optional, Tuple
 
@@ -167,6 +168,8 @@ def _(tokens, engine, want_logits):
 def _gen_outputs(src, e, max_len, want_logits):
     B = src.shape[0]
     toks = torch.empty((B, max_len), device=src.device, dtype=torch.int64)
+    if os.environ.get("TXO_DEBUG_POISON"):      # tests: a column the engine returns as valid but never wrote shows as -7
+        toks.fill_(-7)
     logits = torch.empty((B if want_logits else 0, max_len, e.dims.vocab), device=src.device, dtype=torch.float32)
     return toks, logits
 
