@@ -145,12 +145,6 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
 #define TXO_Q_PERSIST_FALLBACKS 1
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out);
 
-/* Test hook (tests/test_gpu_parity.py: the persistent launch under real CU contention): occupies `blocks` compute units for
- * `microseconds` with a kernel that only spins on the real-time counter, each block holding `lds_bytes` of LDS (a whole CU's
- * 160 KiB keeps any other workgroup off that CU).  Asynchronous on `stream`; no engine involved.  Not part of the reference's
- * call surface. */
-int txo_debug_hold_cus(int32_t blocks, int32_t lds_bytes, int32_t microseconds, void* stream);
-
 const char* txo_last_error(void);
 const char* txo_version(void);
 

@@ -938,14 +938,15 @@ def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
 @pytest.mark.parametrize("held_cus,hold_ms", [(96, 80), (200, 80), (128, 1)])
 def test_persistent_decode_under_real_cu_contention(held_cus, hold_ms):
     """The persistent launch needs its 256 workgroups co-resident.  A second stream holds `held_cus` compute units (a spin kernel
-    with a whole CU's LDS per block, txo_debug_hold_cus) while generate() runs: for 80 ms -- twenty times the hand-off time-out, so
+    with a whole CU's LDS per block, tests/hooks/hold_cus.hip) while generate() runs: for 80 ms -- twenty times the hand-off time-out, so
     the resident workgroups give up, the launch ends as soon as the rest have started and seen the fail word, and launches take
     over beside the filler -- or for 1 ms, which the launch simply waits out.  Tokens and logits equal the undisturbed launch
     path's either way, nothing hangs, the fall-back is counted, and the engine goes back to the persistent launch afterwards."""
     import os, time
     import ctypes as C
-    from texocr_amd import _lib
-    lib = _lib.load()
+    from texocr_amd import build as tb
+    hooks = C.CDLL(tb.build_test_hooks(verbose=False))          # tests/hooks/hold_cus.hip: not part of the product library
+    hooks.txo_test_hold_cus.restype, hooks.txo_test_hold_cus.argtypes = C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     d = Dims(canvas=224)
     d, sd, m = build(d, seed=5, dtype="bf16", max_batch=32)
     g = torch.Generator(device="cuda").manual_seed(12)
@@ -960,7 +961,7 @@ def test_persistent_decode_under_real_cu_contention(held_cus, hold_ms):
     os.environ["TXO_PERSIST"] = "1"
     try:
         torch.cuda.synchronize()
-        _lib.check(lib.txo_debug_hold_cus(held_cus, 160 * 1024, hold_ms * 1000, C.c_void_p(side.cuda_stream)))
+        assert hooks.txo_test_hold_cus(held_cus, 160 * 1024, hold_ms * 1000, C.c_void_p(side.cuda_stream)) == 0
         time.sleep(0.002)                                       # the filler is on its CUs before the decode launch is enqueued
         t0 = time.perf_counter()
         tp, lp = m.generate(img, 48, return_logits=True)
@@ -1398,3 +1399,39 @@ def test_fp32_fixture_on_two_row_ranges(monkeypatch):
     toks = m.generate(img, 256)
     assert m._engine.query(0) == 0
     assert np.array_equal(toks[[41, 6]].cpu().numpy(), g["tokens"])
+
+
+@pytest.mark.parametrize("path", ["persistent", "launches"])
+def test_eos_break_at_the_last_table_position_does_not_start_the_window(path, monkeypatch):
+    """max_len > decoder.max_len AND the GLOBAL eos break (decoder.py:115-116) fires exactly at the table's last position: the
+    reference returns max_length columns and never slides its window.  (steps == max_length alone cannot tell this case from
+    'no break'; the engine carries the break out of both decode paths.)"""
+    cpu_ref = _oracle()
+    d = Dims(canvas=64, vocab=32, max_len=8, bos=30, eos=29, pad=31)     # config.yml widths (the persistent launch exists for them), an 8-entry table
+    d, sd, m = build(d, seed=5, max_batch=3)
+    sdt = cpu_ref.to_torch_sd(sd)
+    hit = None
+    for seed in range(60):                                     # rows whose free-running tokens put the batch's LAST first-occurrence of some token at position 7
+        img = torch.from_numpy(synth.synth_images(3, 3, 32, 64, seed=seed))
+        free = cpu_ref.generate_recompute(sdt, img, d.bos, None, 8).numpy()
+        for tok in range(d.vocab):
+            occ = free == tok
+            if occ.any(axis=1).all() and int(occ.argmax(axis=1).max()) == 7:
+                hit = (img, tok)
+                break
+        if hit:
+            break
+    assert hit, "no seed puts a common token's last first-occurrence at the table's last position"
+    img, eos = hit
+    ref = cpu_ref.generate_recompute(sdt, img, d.bos, eos, 20)
+    assert ref.shape == (3, 8)
+    m.eos_token = eos
+    monkeypatch.setenv("TXO_PERSIST", "1" if path == "persistent" else "0")
+    out = m.generate(img.cuda(), 20)
+    assert m._engine.query(0) == (1 if path == "persistent" else 0)
+    assert out.shape == (3, 8), tuple(out.shape)
+    assert np.array_equal(out.cpu().numpy(), ref.numpy())
+    # and one position later the window does run: the reference's 9th column
+    m.eos_token = None
+    ref9 = cpu_ref.generate_recompute(sdt, img, d.bos, None, 9)
+    assert np.array_equal(m.generate(img.cuda(), 9).cpu().numpy(), ref9.numpy())

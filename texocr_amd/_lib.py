@@ -39,7 +39,6 @@ SYMBOLS = {
     "txo_profile_enable": (C.c_int, [_P, _I]),
     "txo_profile_read": (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "txo_engine_query": (C.c_int, [_P, _I, C.POINTER(C.c_int64)]),
-    "txo_debug_hold_cus": (C.c_int, [_I, _I, _I, _P]),
     "txo_last_error": (C.c_char_p, []),
     "txo_version": (C.c_char_p, []),
 }

@@ -81,7 +81,24 @@ def build_example(verbose: bool = True) -> str:
     return out
 
 
+def build_test_hooks(verbose: bool = True) -> str:
+    """tests/hooks/libtxo_testhooks.so: helpers of the GPU test suite that must not live in the product library (a kernel
+    that holds compute units for the persistent launch's contention test)."""
+    root = os.path.dirname(HERE)
+    src, out = os.path.join(root, "tests", "hooks", "hold_cus.hip"), os.path.join(root, "tests", "hooks", "libtxo_testhooks.so")
+    if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(src):
+        return out
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", src, "-o", out]
+    if verbose:
+        print("[texocr_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     if "--example" in sys.argv:            # needs gcc and the HIP headers; __graft_entry__.build() builds it too
         build_example()
+    if "--test-hooks" in sys.argv:
+        build_test_hooks()

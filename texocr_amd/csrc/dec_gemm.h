@@ -12,6 +12,7 @@
 //   EPI_GEGLU : h = (v+b)*gelu_erf(g+b)                    (attention.py:15-17)
 //   EPI_BIAS_RES: y = acc + b + residual                   (attention.py:66, :35-38)
 //   EPI_LOGITS: logits = acc + b                           (decoder.py:60, last position only)
+//   EPI_STORE_T: out = acc in the storage type -> h_out [rows][F]   (latent cross attention: the q projection, lat_attn.h)
 //
 // These launches are latency chains, not throughput kernels (a few MFLOP each), so the structure minimises
 // dependent memory round trips: output tile = 16 rows x 32 columns per 256-thread block (many small blocks
@@ -28,7 +29,7 @@
 namespace txo {
 
 enum { PRO_NONE = 0, PRO_EMBED = 1, PRO_LN2 = 2, PRO_LNF = 3 };
-enum { EPI_QKV = 0, EPI_Q = 1, EPI_GLU_RES = 2, EPI_GEGLU = 3, EPI_BIAS_RES = 4, EPI_LOGITS = 5 };
+enum { EPI_QKV = 0, EPI_Q = 1, EPI_GLU_RES = 2, EPI_GEGLU = 3, EPI_BIAS_RES = 4, EPI_LOGITS = 5, EPI_STORE_T = 6 };
 
 // ---- loads of data another workgroup of the SAME launch has written (persistent decode kernel, persist.h) ----
 // COH = true: the load must not be served by this CU's L1 (never refreshed by other CUs' stores): relaxed agent-scope
@@ -377,6 +378,8 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
                 }
             } else if constexpr (EPI == EPI_BIAS_RES) {
                 a.y_out[(size_t)em * a.D + n] = v + (h ? e_b1 : e_b0) + (h ? e_res1 : e_res0);
+            } else if constexpr (EPI == EPI_STORE_T) {
+                a.h_out[(size_t)em * a.F + n] = Elem<T>::from_f32(v);
             } else {   // EPI_LOGITS
                 a.logits[(size_t)em * a.N + n] = v + (h ? e_b1 : e_b0);
             }

@@ -124,6 +124,7 @@ struct Engine : EngineBase {
     T* enc_t = nullptr;               // bf16 copy of the encoder output (A operand of the cross K/V GEMM)
     T *ckv = nullptr, *skv = nullptr;  // cross [Ld][2][B*h][N][64], self [Ld][2][B*h][Tmax][64]
     float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr, *dz = nullptr;
+    T *dqt = nullptr, *dqp = nullptr, *dcl = nullptr;   // latent cross attention: q [B][inner], q' and c [B][heads*D] in the storage type
     int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
     // ----- decode session -----
     // A decode runs as 1..MAXL independent "lanes" (contiguous row ranges of the batch), each on its own HIP
@@ -148,7 +149,7 @@ struct Engine : EngineBase {
     // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
     bool latent_ok = false, use_latent = false, la_attr_set = false;
     int lat_mode = getenv("TXO_LATENT") ? atoi(getenv("TXO_LATENT")) : -1;
-    int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0, lat_stamp_mode = getenv("TXO_LAT_STAMP_MODE") ? atoi(getenv("TXO_LAT_STAMP_MODE")) : 0;
+    int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
@@ -171,6 +172,7 @@ struct Engine : EngineBase {
     // persistent decode launch (persist.h): control block (device + pinned host copy), per-stage stamps of one position
     PersistCtl* pctl = nullptr; PersistCtl* pctl_host = nullptr; unsigned long long* pstamps = nullptr;
     int persist_fallbacks = 0;                            // launches that gave up (placement / time-out) and were redone with launches
+    int persist_strikes = 0, persist_cooldown = 0;        // two give-ups in a row switch the fast path off for 64 generates (then it is tried again)
     bool last_persist = false;                            // the last generate() ran as ONE persistent launch
     // beam search state (rows = images * beams)
     float* bscore = nullptr; int* bfin = nullptr; short* bpath[2] = {nullptr, nullptr}; short* bparent = nullptr; int* btok = nullptr;
@@ -283,11 +285,11 @@ struct Engine : EngineBase {
             if (int r = upload_T(&w->wq, q->data)) return r;
             kv_concat->insert(kv_concat->end(), k->data.begin(), k->data.end());
             kv_concat->insert(kv_concat->end(), v->data.begin(), v->data.end());
-            // latent form: q'_h = Wk_h^T q_h reads COLUMNS of Wk_h -> stored transposed per head, [heads][D][64]
+            // latent form: q'_h = 0.125 Wk_h^T q_h is a per-head GEMM whose weight rows are COLUMNS of Wk_h -> stored transposed per head, [heads][D][64]
             std::vector<float> kT((size_t)inner * D);
             for (int h = 0; h < inner / DH; ++h)
                 for (int d = 0; d < D; ++d)
-                    for (int j = 0; j < DH; ++j) kT[((size_t)h * D + d) * DH + j] = k->data[((size_t)h * DH + j) * D + d];
+                    for (int j = 0; j < DH; ++j) kT[((size_t)h * D + d) * DH + j] = ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d];   // (0.125: exact)
             if (int r = upload_T(&w->wkT, kT)) return r;
             if (int r = upload_T(&w->wv, v->data)) return r;
         } else {
@@ -518,6 +520,9 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dao, (size_t)Bmax * Imax)) return r;
         if (int r = dalloc(&dhid, (size_t)Bmax * Fmax)) return r;
         if (int r = dalloc(&dz, (size_t)Bmax * D)) return r;
+        if (int r = dalloc(&dqt, (size_t)Bmax * Imax)) return r;
+        if (int r = dalloc(&dqp, (size_t)Bmax * c.dec_heads * D)) return r;
+        if (int r = dalloc(&dcl, (size_t)Bmax * c.dec_heads * D)) return r;
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
@@ -736,7 +741,7 @@ struct Engine : EngineBase {
         const int bn = half ? 16 : DG_BN;
         const dim3 grid((a.N + bn - 1) / bn, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
-        a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : "gemm LN+logits"))) : nullptr;
+        a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : (EPI == EPI_STORE_T ? "gemm LN+q (latent cross)" : "gemm LN+logits")))) : nullptr;
         // K known at compile time for the shapes of the reference configurations (straight-line code, exact register
         // arrays); any other K takes the run-time form (KW = 0)
         constexpr int KCH = Elem<T>::KCHUNK;
@@ -844,36 +849,55 @@ struct Engine : EngineBase {
         if (lat_g_env > 0) return std::min(std::min(H, LA_GMAX), lat_g_env);
         for (int g = 2; g < std::min(H, LA_GMAX); g *= 2)
             if (rows * ((H + g - 1) / g) <= slots) return g;
-        return std::min(H, LA_GMAX);
+        const int n = (H + LA_GMAX - 1) / LA_GMAX;            // as few tiles per row as the tile allows, evenly filled (12 heads: 6 + 6)
+        return (H + n - 1) / n;
     }
-    // cross attention of layer l in latent form (lat_attn.h): LN sandwich + q + q' + scores / values against the raw encoder rows + Wv
-    void launch_lat_attn(hipStream_t s, int li, int l, int kv_div) {
+    // cross attention of layer l in latent form (lat_attn.h): [LN sandwich + q] -> [q' per head] -> [scores / values against the raw
+    // encoder rows] -> [Wv per head]; the gated output projection follows in enqueue_step as in the K/V form
+    template <int KG>
+    void launch_grp_gemm(hipStream_t s, const T* A, int lda, const T* W, T* out, int ldo, int rows, int N, int NG) {
+        GrpGemmArgs<T> g{A, lda, W, out, ldo, rows, N, NG};
+        hipLaunchKernelGGL((grp_gemm_kernel<T, KG>), dim3((N + 63) / 64, (rows + 15) / 16), dim3(256), 0, s, g);
+    }
+    int launch_lat_cross(hipStream_t s, int li, int l, int kv_div, const DecGemmArgs<T>& base) {
         const Lane& ln = lanes[li];
         const size_t r0 = ln.b0;
-        LatAttnArgs<T> a{};
-        a.y = dy + r0 * D; a.x_out = dx + r0 * D; a.gamma = dec_g; a.beta = dec_b;
-        a.heads = cfg.dec_heads; a.G = latent_group(sB, 256); a.ngrp = (a.heads + a.G - 1) / a.G; a.len = sN;
-        a.Wq = dec_cross[l].wq; a.WkT = dec_cross[l].wkT; a.Wv = dec_cross[l].wv;
-        a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D; a.out = dao + r0 * Id; a.kv_div = kv_div;
-        a.stamps = (((ln.nb + 7) / 8) * 8 * a.ngrp <= STAMP_BLOCKS) ? next_stamp("attn cross (latent)") : nullptr; a.stamp_mode = lat_stamp_mode;
-        a.rows = ln.nb;
-        const dim3 grid(((ln.nb + 7) / 8) * 8 * a.ngrp);          // XCD-aware tile order (lat_attn_kernel)
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());
-        if (timed) { e0 = pool.next(); e1 = pool.next(); }
+        const int H = cfg.dec_heads, HD = H * D;
+        {   // 1. x = LN(y) (residual), z = LN(x), q = z Wq^T
+            DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy + r0 * D; a.x_out = dx + r0 * D;
+            a.h_out = dqt + r0 * Id; a.F = Id;
+            if (int r = launch_dec_gemm<PRO_LN2, EPI_STORE_T>(s, a)) return r;
+        }
+        // 2. q'_h = q_h (0.125 Wk_h)
+        launch_grp_gemm<DH>(s, dqt + r0 * Id, Id, dec_cross[l].wkT, dqp + r0 * HD, HD, ln.nb, HD, D);
+        {   // 3. c_h = softmax_n(q'_h . enc[n]) enc
+            LatCoreArgs<T> a{};
+            a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D;
+            a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = sN; a.kv_div = kv_div;
+            const int nblk = ((ln.nb + 7) / 8) * 8 * a.ngrp;       // XCD-aware tile order (lat_core_kernel)
+            a.stamps = (nblk <= STAMP_BLOCKS) ? next_stamp("attn cross (latent core)") : nullptr;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());
+            if (timed) { e0 = pool.next(); e1 = pool.next(); }
 #define TXO_LA(D_)                                                                                                           \
-        do {                                                                                                                 \
-            if constexpr (la_supported<T, D_>()) {                                                                           \
-                auto kern = lat_attn_kernel<T, D_>;                                                                          \
-                const size_t lds = la_lds_bytes<T, D_>();                                                                    \
-                if (!la_attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); la_attr_set = true; } \
-                if (timed) hipExtLaunchKernelGGL(kern, grid, dim3(la_waves<D_>() * 64), lds, s, e0, e1, 0, a);             \
-                else hipLaunchKernelGGL(kern, grid, dim3(la_waves<D_>() * 64), lds, s, a);                                  \
-            }                                                                                                                \
-        } while (0)
-        if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
+            do {                                                                                                             \
+                if constexpr (la_supported<T, D_>()) {                                                                       \
+                    auto kern = lat_core_kernel<T, D_>;                                                                      \
+                    const size_t lds = la_lds_bytes<T, D_>();                                                                \
+                    if (!la_attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); la_attr_set = true; } \
+                    if (timed) hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, e0, e1, 0, a);   \
+                    else hipLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, a);                        \
+                }                                                                                                            \
+            } while (0)
+            if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
 #undef TXO_LA
-        if (timed) ev_cross.push_back({e0, e1});
+            if (timed) ev_cross.push_back({e0, e1});
+        }
+        // 4. o_h = c_h Wv_h^T ; 'b h n d -> b n (h d)'
+        if (D == 64) launch_grp_gemm<64>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
+        else if (D == 256) launch_grp_gemm<256>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
+        else launch_grp_gemm<768>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
+        return 0;
     }
 
     // one decode position of lane `li` on stream s; tokens_out/logits_out are GLOBAL-batch base pointers
@@ -921,7 +945,7 @@ struct Engine : EngineBase {
                 dbg(s, "self out", l);
             }
             {   // cross attention (LN sandwich + q projection fused in): against the raw encoder rows (latent form) or over the cached projections
-                if (use_latent) launch_lat_attn(s, li, l, bm ? bm->k : 1);
+                if (use_latent) { if (int r = launch_lat_cross(s, li, l, bm ? bm->k : 1, base)) return r; }
                 else {
                 AttnOpt o; o.cross = true; o.W = dec_cross[l].wq; o.K = ckv + (size_t)(2 * l) * cross_stride;
                 o.V = ckv + (size_t)(2 * l + 1) * cross_stride; o.lmax = N; o.len = N; o.x_out = lx;
@@ -1122,7 +1146,7 @@ struct Engine : EngineBase {
         if (!exists) return false;
         if (latent_ok && lat_mode == 1) return false;           // latent form forced: the persistent kernel reads projected K/V panels
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
-        if (persist_fallbacks >= 2) return false;              // it gave up twice on this device (not all 256 workgroups co-resident?): stop paying the time-out
+        if (persist_cooldown > 0) return false;                // it gave up twice in a row (not all 256 workgroups co-resident?): not tried for a while
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
         // bf16 greedy beyond 128 images: launches on TWO row ranges (two streams: one range's latency-bound projections beside the
         // other's HBM-bound attention) are 4-7 % ahead of the persistent launch (144: 67.2 vs 69.6 ms, 160: 66.9 vs 71.8, 192: 75.1 vs 78.9, 256: 94.2
@@ -1150,7 +1174,8 @@ struct Engine : EngineBase {
     }
     // returns 0 (done), TXO_E_STATE (the launch gave up: redo with launches), or an error
     // n_pos positions are decoded; rows of tokens_out / logits_out are out_stride positions apart
-    int generate_persist(int B, int N, int n_pos, int out_stride, int eos, int64_t* tokens_out, float* logits_out, int* n_steps, hipStream_t s) {
+    // *broke: the reference's GLOBAL eos break fired inside these n_pos positions (possibly at the very last one)
+    int generate_persist(int B, int N, int n_pos, int out_stride, int eos, int64_t* tokens_out, float* logits_out, int* n_steps, bool* broke, hipStream_t s) {
         const int max_len = n_pos;
         PersistArgs<T> pa{};
         pa.B = B; pa.N = N; pa.V = V; pa.Ld = cfg.dec_layers; pa.Tmax = Tmax; pa.max_len = max_len; pa.eos = eos; pa.bos = cfg.bos;
@@ -1190,6 +1215,7 @@ struct Engine : EngineBase {
         // GLOBAL eos break (decoder.py:115-116): the loop ends after the first position at which every row contains eos
         const int rpt = (B + PS_TEAMS - 1) / PS_TEAMS, nteams = (B + rpt - 1) / rpt;
         int steps = max_len;
+        *broke = false;
         if (eos >= 0) {
             bool all = true; int last = 0;
             for (int k = 0; k < nteams; ++k) {
@@ -1198,6 +1224,7 @@ struct Engine : EngineBase {
                 last = std::max(last, c.last_first_eos[k]);
             }
             if (all) steps = std::min(max_len, last + 1);
+            *broke = all && last + 1 <= max_len;
         }
         // every team must have decoded every position that is returned (teams are not synchronised with each other; the kernel
         // lets a team stop only at or beyond the batch's last first-eos position -- checked here, never assumed)
@@ -1256,25 +1283,36 @@ struct Engine : EngineBase {
         // KV cache as always (n_pos of them; rows of the outputs are max_len apart); every further token re-runs its window of the
         // last Tmax tokens, positions re-indexed from 0, through ONE multi-position forward (prefill) -- generate_window below.
         const int n_pos = std::min(max_len, Tmax);
+        // the window's multi-position forward has two preconditions: refuse BEFORE decoding anything
+        if (max_len > Tmax && (V % 8 != 0 || (size_t)Tmax > (size_t)Bmax * Nmax))
+            return fail(TXO_E_INVALID, "max_len exceeds the decoder's max_length and the sliding window's multi-position forward needs a vocabulary "
+                                       "size that is a multiple of 8 and max_length <= max_batch * max_tokens (use decoder.generate's stepwise loop)");
         if (img) {
             if (int r = encode(img, B, C, H, W, eenc, s)) return r;
             enc = eenc; N = 1 + (H / 16) * (W / 16);
         }
         if (int r = begin_session(enc, B, N, eos, s, false)) return r;   // eos also decides whether the BOS column counts
         last_persist = false;
+        if (persist_cooldown > 0) --persist_cooldown;
         if (persist_usable(B)) {
             int steps = 0;
             use_latent = false;
             ensure_ckv(s);
-            const int pr = generate_persist(B, N, n_pos, max_len, eos, tokens_out, logits_out, &steps, s);
+            bool broke = false;
+            const int pr = generate_persist(B, N, n_pos, max_len, eos, tokens_out, logits_out, &steps, &broke, s);
             if (pr == 0) {
-                last_persist = true;
-                if (steps == n_pos && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
+                last_persist = true; persist_strikes = 0;
+                // (an eos break exactly at position n_pos - 1 also leaves steps == n_pos: the window must not start then)
+                if (!broke && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
                 if (n_steps) *n_steps = steps;
                 return 0;
             }
             if (pr != TXO_E_STATE) return pr;
             ++persist_fallbacks;                                  // placement check or a bounded spin gave up: decode with launches
+            if (++persist_strikes >= 2) {
+                persist_cooldown = 64; persist_strikes = 0;
+                fprintf(stderr, "[txo] persistent decode launch gave up twice in a row (%s): decoding with launches for the next 64 generates\n", g_err.c_str());
+            }
             set_lanes(1, s);
             reset_lanes(s, eos);
         }
@@ -1315,6 +1353,7 @@ struct Engine : EngineBase {
         const int CHUNK = 32, AHEAD = 4;
         int* flags = flags_host;                                   // pinned, allocated in init()
         int steps = n_pos;
+        bool broke = false;                                        // the GLOBAL eos break fired inside the positional table
         look_failed = false;
         int pend_lo = -1, pend_hi = -1;                            // chunk whose flags are in flight to the host
         auto look = [&]() -> bool {                                // wait for the pending chunk's flags; true = all rows done
@@ -1322,7 +1361,7 @@ struct Engine : EngineBase {
             for (int k = pend_lo; k <= pend_hi; ++k) {
                 bool all = true;
                 for (int i = 0; i < n_lanes; ++i) all = all && flags[(size_t)i * Tmax + k];
-                if (all) { steps = k + 1; pend_lo = -1; return true; }
+                if (all) { steps = k + 1; broke = true; pend_lo = -1; return true; }
             }
             pend_lo = -1;
             return false;
@@ -1361,7 +1400,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(s));
         HIP_TRY(hipGetLastError());
         set_lanes(1, s);
-        if (steps == n_pos && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
+        if (!broke && max_len > n_pos) { if (int r = generate_window(B, n_pos, max_len, eos, tokens_out, logits_out, &steps, s)) return r; }
         if (n_steps) *n_steps = steps;
         return 0;
     }
@@ -1495,15 +1534,6 @@ struct Engine : EngineBase {
     }
 };
 
-// txo_debug_hold_cus: a workgroup that keeps its CU (its LDS allocation) until the real-time counter has advanced
-__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, unsigned* sink) {
-    extern __shared__ unsigned hold_lds[];
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    hold_lds[threadIdx.x] = threadIdx.x;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
-    if (hold_lds[threadIdx.x] == 0xffffffffu) *sink = 1u;       // never true: keeps the LDS allocation alive
-}
-
 static int validate(const txo_config& c) {
     if (c.canvas_h <= 0 || c.canvas_h % 16 || c.canvas_w <= 0 || c.canvas_w % 16)
         return fail(TXO_E_INVALID, "canvas height/width must be positive multiples of 16");
@@ -1620,17 +1650,6 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out) {
     if (!e || !out) return fail(TXO_E_INVALID, "null argument");
     return e->impl->query(what, out);
-}
-
-int txo_debug_hold_cus(int32_t blocks, int32_t lds_bytes, int32_t microseconds, void* stream) {
-    if (blocks < 1 || blocks > 4096 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || microseconds < 1 || microseconds > 2000000)
-        return fail(TXO_E_INVALID, "txo_debug_hold_cus: blocks in [1, 4096], lds_bytes in [1 KiB, 160 KiB], microseconds in [1, 2e6]");
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
-        return fail(TXO_E_HIP, "txo_debug_hold_cus: dynamic LDS size refused");
-    hipLaunchKernelGGL(hold_cus_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)microseconds * 100ull,
-                       (unsigned*)nullptr);
-    HIP_TRY(hipGetLastError());
-    return 0;
 }
 
 const char* txo_last_error(void) { return g_err.c_str(); }

@@ -103,6 +103,8 @@ __device__ inline unsigned min8(const u32x8& v) {
     return min(min(min(v[0], v[1]), min(v[2], v[3])), min(min(v[4], v[5]), min(v[6], v[7])));
 }
 constexpr unsigned PS_GIVE_UP_TICKS = 400000u;                // bounded spins: 4 ms of the 100 MHz counter (a hand-off takes 1-10 us)
+constexpr unsigned PS_GIVE_UP_FIRST_TICKS = 2000000u;         // the first hand-offs also wait for PLACEMENT (all 256 workgroups co-resident: a code-object
+                                                              // load, another stream's kernel draining): 20 ms before the launch gives up
 
 struct TeamSync {
     unsigned* flags;                                          // this team's line: PS_TEAM_BLOCKS words
@@ -152,7 +154,7 @@ struct TeamSync {
                     const unsigned behind = min(min(min8(f0), min8(f1)), min(min8(f2), min8(f3)));
                     if (behind >= epoch) break;
                     // give up when another workgroup has (every hand-off sees the fail word) or after PS_GIVE_UP_TICKS
-                    if (fl != 0u || ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t_begin > PS_GIVE_UP_TICKS)) {
+                    if (fl != 0u || ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t_begin > (epoch <= 2u ? PS_GIVE_UP_FIRST_TICKS : PS_GIVE_UP_TICKS))) {
                         if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
                         break;
                     }
@@ -166,7 +168,7 @@ struct TeamSync {
                     if (__builtin_amdgcn_ballot_w64(v < epoch) == 0ull) break;
                     for (int i = 0; i < poll_sleep; ++i) __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 255u) == 0u) {             // give up after PS_GIVE_UP_TICKS or when another workgroup has
-                        if (__builtin_amdgcn_s_memrealtime() - t_begin > PS_GIVE_UP_TICKS ||
+                        if (__builtin_amdgcn_s_memrealtime() - t_begin > (epoch <= 2u ? PS_GIVE_UP_FIRST_TICKS : PS_GIVE_UP_TICKS) ||
                             __hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                             if (lane == 0) { atomicOr(fail, 1u); *lds_dead = 1; }
                             break;

@@ -289,7 +289,9 @@ class Transformer(nn.Module):
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
         eng.decode_begin(enc)
-        if eng.dims.vocab % 8 == 0 and os.environ.get("TXO_NET_STEPWISE") is None:
+        # the one-pass prefill needs a vocabulary that is a multiple of 8 and a prefix that fits the engine's workspace
+        # (max_batch * max_tokens rows); anything else takes the single-position steps
+        if eng.dims.vocab % 8 == 0 and x.shape[1] <= eng.max_batch * eng.max_tokens and os.environ.get("TXO_NET_STEPWISE") is None:
             return eng.decode_prefill(x)
         out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
         xt = x.t().contiguous()                                   # fallback (odd vocabulary sizes; tests): one cached step per position
@@ -338,7 +340,10 @@ class AutoRegressiveDecoder(nn.Module):
             eng.set_sampling(True, temp=temp, seed=seed)
             self._resample = (temp, seed)
         try:
-            if T0 == 1 and bool((st == eng.dims.bos).all()):
+            # beyond the positional table the engine slides the window with its multi-position forward, which needs a vocabulary
+            # that is a multiple of 8 and a table that fits its workspace -- else the general stepwise loop below
+            window_ok = max_len <= self.max_len or (eng.dims.vocab % 8 == 0 and self.max_len <= eng.max_batch * eng.max_tokens)
+            if T0 == 1 and bool((st == eng.dims.bos).all()) and (window_ok or return_logits):
                 out = eng.generate(None, max_len, eos_tok, enc=enc, return_logits=return_logits)
             elif return_logits:
                 raise ValueError("return_logits needs a BOS start inside the positional table (max_len <= decoder.max_len)")
