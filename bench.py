@@ -200,17 +200,37 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
     out = {"value": round(B / sec, 2), "unit": "images/sec", "ms_per_step": round(1000 * sec, 3), "batch": B, "dtype": dtype, "steps": steps}
     esz = 2 if dtype == "bf16" else 4
     eng = m._engine
-    out["decode_path"] = "one persistent launch (csrc/persist.h)" if eng.query(0) == 1 else "one launch per stage"
+
+    def path_label():
+        if eng.query(0) == 1:
+            return "one persistent launch (csrc/persist.h), cross attention over projected K/V panels"
+        form = "latent form (csrc/lat_attn.h: against the raw encoder rows)" if eng.query(3) == 1 else "projected K/V panels (csrc/dec_attn.h)"
+        rng = eng.query(2)
+        return (f"one launch per stage, {rng} row range{'s' if rng > 1 else ''} on {rng} stream{'s' if rng > 1 else ''}; cross attention: {form}")
+    out["decode_path"] = path_label()
     if want_cross:
+        # the cross-attention launch of ONE whole-batch range (profiling decodes on a single stream: with two row ranges the two
+        # half-batch launches overlap each other and neither duration is the kernel's own)
         eng.profile(2)
         m.generate(img, a.max_len)
         torch.cuda.synchronize()
         ms, n = eng.profile_read(0)
+        latent = eng.query(3) == 1
         eng.profile(0)
-        algo = B * dims.dec_heads * 2 * N * 64 * esz
+        algo_kv = B * dims.dec_heads * 2 * N * 64 * esz                     # K and V panels of every (image, head) once
+        algo_lat = B * N * dims.embed_dim * esz                             # the raw encoder rows once for all heads (+ q', c: < 1 %)
+        algo = algo_lat if latent else algo_kv
         ach = algo / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        out["roofline"] = {"kernel": "dec_attn_kernel (decode-step cross-attention; a separate generate() on the launch-per-stage path)", "bound": "hbm", "achieved": round(ach, 1),
-                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "frac_of_achievable_6300": round(ach / 6300.0, 4), "algorithmic_bytes_per_launch": algo,
+        out["roofline"] = {"kernel": ("lat_core_kernel (decode-step cross attention in latent form: scores and values against the raw encoder rows)" if latent
+                                      else "dec_attn_kernel (decode-step cross-attention over projected K/V panels)"),
+                           "timed_over": "a separate generate() with dispatch-bound HIP events on every fourth cross-attention launch; the profiling "
+                                         "decode runs the whole batch as ONE row range on one stream (the throughput above: see decode_path)",
+                           "bound": "hbm", "achieved": round(ach, 1),
+                           "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "frac_of_achievable_6300": round(ach / 6300.0, 4),
+                           "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_kv_form": algo_kv, "algorithmic_bytes_latent_form": algo_lat,
+                           "algorithmic_bytes": "the bytes of the form that ran (frac cannot exceed 1); kv_form = B*heads*2*N*64*s (SURVEY 8d), "
+                                                "latent_form = B*N*D*s",
+                           "kv_form_equivalent_GBps": round(algo_kv / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
                            "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n}
     if want_encoder:
         eng.profile(True)
@@ -317,14 +337,15 @@ def main():
                                    f"batch {a.batch}/GPU, {a.height}x{a.width}, greedy max_len={a.max_len}",
                        "global_batch": a.batch * world, "tokens_per_image": N,
                        "parallelism": f"dp{world} (images sharded, " + ("one RCCL all-gather of token ids per step" if dist_on else "single process, no collective") + ")",
-                       "decode_path": "persistent launch (csrc/persist.h)" if persistent else "one launch per stage"},
+                       "decode_path": "persistent launch (csrc/persist.h)" if persistent else
+                                      (f"one launch per stage, {eng.query(2)} row range(s); cross attention in " + ("latent form" if eng.query(3) == 1 else "K/V form"))},
         }
         if not a.no_roofline:
             Ld, heads = dims.dec_layers, dims.dec_heads
             algo_cross = a.batch * heads * 2 * N * 64 * esz                 # one cross-attention launch / stage: K and V panels once
             mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3              # dense TFLOP/s, MI355X_MICROARCH.md
             def pmc(kind):
-                for rnd in ("r03", "r02", "r01"):
+                for rnd in ("r04", "r03", "r02", "r01"):
                     fn = os.path.join("profiles", f"{rnd}_pmc_{kind}{a.dtype}_b{a.batch}.json")
                     try:
                         pm = json.load(open(os.path.join(ROOT, fn)))["traffic"]
@@ -347,7 +368,12 @@ def main():
                     "frac_of_achievable_6300": round(ach / 6300.0, 4),     # the same against the ~6.3 TB/s a streaming kernel reaches
                     "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo,
                     "algorithmic_bytes": "cross-attention K/V panels + self-attention history read once per position and layer "
-                                         "(weights and activations stay in L2 / Infinity Cache)",
+                                         "(weights and activations stay in L2 / Infinity Cache): the bytes of the K/V FORM this kernel computes in",
+                    # the latent form of the cross attention (csrc/lat_attn.h, what runs beyond 128 images) needs N*D instead of 2*N*heads*64
+                    # elements per (image, layer, position): against THOSE bytes this launch is at frac_latent_form_bytes
+                    "algorithmic_bytes_latent_form": a.batch * esz * Ld * sum(N * dims.embed_dim + 2 * (t + 1) * heads * 64 for t in range(a.max_len)),
+                    "frac_latent_form_bytes": round(a.batch * esz * Ld * sum(N * dims.embed_dim + 2 * (t + 1) * heads * 64 for t in range(a.max_len))
+                                                    / (ms_live * 1e-3) / 1e9 / 8000.0, 4) if ms_live > 0 else 0.0,
                     "avg_launch_us": round(ms_live * 1e3, 1), "launches_timed": n_live,
                     "timed_over": "the last of the K timed steps (HIP events bound to the dispatch)",
                     "us_per_position": round(ms_live * 1e3 / a.max_len, 2)}
@@ -359,6 +385,7 @@ def main():
                 model.generate(imgs[0], a.max_len)
                 torch.cuda.synchronize()
                 ms_x, n_x = eng.profile_read(0)
+                lat_x = eng.query(3) == 1                               # beyond 128 images the launches run the cross attention in latent form
                 eng.profile(True)
                 model.generate(imgs[0], a.max_len)
                 torch.cuda.synchronize()
@@ -368,7 +395,7 @@ def main():
             finally:
                 os.environ.pop("TXO_PERSIST")
             traffic, tsrc = None, None
-            for rnd in ("r03", "r02", "r01"):
+            for rnd in ("r04", "r03", "r02", "r01"):
                 fn = os.path.join("profiles", f"{rnd}_pmc_{a.dtype}_b{a.batch}.json")
                 try:
                     pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]
@@ -377,8 +404,14 @@ def main():
                         break
                 except Exception:
                     pass
+            algo_kv_x = algo_cross
+            if lat_x:
+                algo_cross = a.batch * N * dims.embed_dim * esz             # latent form: the raw encoder rows once for all heads
+                traffic, tsrc = None, None
             ach_x = algo_cross / (ms_x * 1e-3) / 1e9 if ms_x > 0 else 0.0
-            cross = {"kernel": "dec_attn_kernel (decode-step cross-attention, launch-per-stage path)", "bound": "hbm",
+            cross = {"kernel": ("lat_core_kernel (decode-step cross attention in latent form, launch-per-stage path)" if lat_x else
+                                "dec_attn_kernel (decode-step cross-attention, launch-per-stage path)"), "bound": "hbm",
+                     "algorithmic_bytes_kv_form": algo_kv_x, "algorithmic_bytes_latent_form": a.batch * N * dims.embed_dim * esz,
                      "achieved": round(ach_x, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach_x / 8000.0, 4), "frac_of_achievable_6300": round(ach_x / 6300.0, 4),
                      "traffic": traffic, "traffic_source": tsrc, "algorithmic_bytes_per_launch": algo_cross,
                      "avg_launch_us": round(ms_x * 1e3, 2), "launches_timed": n_x,

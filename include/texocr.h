@@ -143,6 +143,8 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
  * many persistent launches gave up (placement check / bounded spin) and were redone with launches since the engine was created. */
 #define TXO_Q_LAST_PERSISTENT 0
 #define TXO_Q_PERSIST_FALLBACKS 1
+#define TXO_Q_LAST_ROW_RANGES 2   /* row ranges (streams) the last generate decoded on: 1, or 2 beyond 128 images in bf16 (launch path) */
+#define TXO_Q_LAST_LATENT 3       /* 1 if the last generate's cross attention ran in latent form (csrc/lat_attn.h: against the raw encoder rows) */
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out);
 
 const char* txo_last_error(void);

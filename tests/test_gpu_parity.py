@@ -1321,9 +1321,9 @@ def test_bf16_benchmark_shape_vs_reference_every_position(form, monkeypatch):
     worst = float(g["margin"][flips].max()) if flips.any() else 0.0
     print(f"cfg2 t256 bf16 ({form} form) vs reference, teacher-forced 2x256: max |dlogit| over the reference's top-5 {err:.4f}, "
           f"top-1 agreement {agree:.4f}, largest reference margin among the flipped positions {worst:.4f}")
-    assert err < 0.035, err                                    # 1.5x the measurement (r04: K/V form 0.0228 / 0.9941, latent form 0.0220 / 0.9902)
-    assert agree > 0.985, agree
-    assert worst < 2 * 0.035                                   # a flip needs a margin thinner than twice the logit error (measured: <= 0.0082)
+    assert err < 0.038, err                                    # 1.5x the measurement (r04: K/V form 0.0228 / 0.9941, latent form 0.0251 / 0.9883)
+    assert agree > 0.982, agree
+    assert worst < 2 * 0.038                                   # a flip needs a margin thinner than twice the logit error (measured: <= 0.0082)
 
 
 @pytest.mark.parametrize("path", ["persistent", "launches"])

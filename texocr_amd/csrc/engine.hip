@@ -104,7 +104,8 @@ struct Engine : EngineBase {
     std::vector<void*> allocs;
     struct AttnW { T* wqkv = nullptr; T* wq = nullptr; T* wo = nullptr; float* bo = nullptr;
                    T* wo16 = nullptr; float* bo16 = nullptr;    // decoder: second copy interleaved by 16 (prefill: the large-GEMM epilogues)
-                   T* wkT = nullptr; T* wv = nullptr; };        // decoder cross attention, latent form (lat_attn.h): Wk per head transposed [heads][D][64], Wv [inner][D]
+                   T* wkT = nullptr; T* wv = nullptr;   
+                   T* wqp = nullptr; T* wo_f = nullptr; };      // ... folded where inner == 2 D: q' = z (0.125 Wk_h^T Wq_h)^T [heads*D][D]; Wo' = Wo blockdiag(Wv_h) [2D][heads*D], rows interleaved by 8        // decoder cross attention, latent form (lat_attn.h): Wk per head transposed [heads][D][64], Wv [inner][D]
     struct MlpW { T* w1 = nullptr; float* b1 = nullptr; T* w2 = nullptr; float* b2 = nullptr;
                   T* w1_16 = nullptr; float* b1_16 = nullptr; };   // decoder, wide rows: second copy interleaved by 16 (large-batch FFN-in)
     float *cls = nullptr, *pos = nullptr, *patch_b = nullptr; T* patch_w = nullptr;
@@ -174,6 +175,7 @@ struct Engine : EngineBase {
     int persist_fallbacks = 0;                            // launches that gave up (placement / time-out) and were redone with launches
     int persist_strikes = 0, persist_cooldown = 0;        // two give-ups in a row switch the fast path off for 64 generates (then it is tried again)
     bool last_persist = false;                            // the last generate() ran as ONE persistent launch
+    int last_ranges = 1;                                  // row ranges (streams) the last launch-path decode ran on
     // beam search state (rows = images * beams)
     float* bscore = nullptr; int* bfin = nullptr; short* bpath[2] = {nullptr, nullptr}; short* bparent = nullptr; int* btok = nullptr;
     struct BeamCtx { int k; const short* path_cur; short* path_nxt; };
@@ -292,6 +294,37 @@ struct Engine : EngineBase {
                     for (int j = 0; j < DH; ++j) kT[((size_t)h * D + d) * DH + j] = ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d];   // (0.125: exact)
             if (int r = upload_T(&w->wkT, kT)) return r;
             if (int r = upload_T(&w->wv, v->data)) return r;
+            if (latent_fold()) {
+                // inner == 2 D (config.yml dims: 8 heads of 64 at width 256): both per-head projections fold into their neighbours at load
+                // time (products in double, rounded once to the storage type) and the sub-layer is THREE launches instead of five:
+                //   q'[h*D + d'] = sum_d z[d] * M[h*D + d'][d],   M = 0.125 Wk_h^T Wq_h            (in the LN-prologue GEMM, N = heads*D)
+                //   y[n]         = sum_{h,d} c[h*D + d] * Wo'[n][h*D + d],  Wo' = Wo[:, h] Wv_h     (in the gated output projection, K = heads*D)
+                const int H = inner / DH, HD = H * D;
+                std::vector<float> M((size_t)HD * D), WoF((size_t)2 * D * HD);
+                std::vector<double> acc(std::max(D, HD));
+                for (int h = 0; h < H; ++h)
+                    for (int d1 = 0; d1 < D; ++d1) {
+                        std::fill(acc.begin(), acc.begin() + D, 0.0);
+                        for (int j = 0; j < DH; ++j) {
+                            const double kk = (double)ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d1];
+                            const float* qr = &q->data[((size_t)h * DH + j) * D];
+                            for (int d = 0; d < D; ++d) acc[d] += kk * qr[d];
+                        }
+                        for (int d = 0; d < D; ++d) M[((size_t)h * D + d1) * D + d] = (float)acc[d];
+                    }
+                for (int n = 0; n < 2 * D; ++n) {
+                    std::fill(acc.begin(), acc.begin() + HD, 0.0);
+                    for (int f = 0; f < inner; ++f) {
+                        const double wn = wo->data[(size_t)n * inner + f];
+                        const float* vr = &v->data[(size_t)f * D];
+                        double* dst = &acc[(size_t)(f / DH) * D];
+                        for (int d = 0; d < D; ++d) dst[d] += wn * vr[d];
+                    }
+                    for (int c2 = 0; c2 < HD; ++c2) WoF[(size_t)n * HD + c2] = (float)acc[c2];
+                }
+                if (int r = upload_T(&w->wqp, M)) return r;
+                if (int r = upload_T(&w->wo_f, interleave(WoF, D, HD, G))) return r;
+            }
         } else {
             std::vector<float> cat(q->data);
             cat.insert(cat.end(), k->data.begin(), k->data.end());
@@ -393,8 +426,9 @@ struct Engine : EngineBase {
             for (auto& kv : host) bytes += kv.second.data.size() * sizeof(float) + 512;
             // + the decoder's second (16-interleaved) copies of the gated projections for the prefill
             bytes += (size_t)cfg.dec_layers * ((size_t)2 * 2 * D * Id + (size_t)2 * Fd * D + 4 * D + 2 * Fd + 4096) * sizeof(float);
-            // + the latent form's copies of the cross-attention Wk (transposed per head) and Wv
+            // + the latent form's copies of the cross-attention Wk (transposed per head) and Wv, and the folded pair where inner == 2 D
             bytes += (size_t)cfg.dec_layers * ((size_t)2 * D * Id + 1024) * sizeof(float);
+            if (latent_fold()) bytes += (size_t)cfg.dec_layers * ((size_t)3 * cfg.dec_heads * D * D + 1024) * sizeof(float);
             if (int r = arena_begin(bytes + (1u << 20))) return r;
         }
         const int npos = 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
@@ -841,6 +875,8 @@ struct Engine : EngineBase {
     // cross-attention launch 49 -> 32 us, 2700 -> 3290 images/s).  Up to 128 rows the persistent kernel decodes (K/V form: at one
     // (row, head group) tile per CU the latent tile moves 493 KB per CU against 300 KB and is slower, 19 vs 16 us per launch at batch
     // 64); wide decoders (768: the in-tile projections' weights are 3.4 MB per row) and the fp32 parity mode keep the K/V form.
+    // the latent form's two per-head projections fold into their neighbouring GEMMs (load_attn) where the folded weights stay small
+    bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D && getenv("TXO_LAT_NOFOLD") == nullptr; }
     bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY && !sample_mode; }
     // heads per latent tile: the smallest group that leaves at most one tile per CU for `rows` rows (fewer tiles = fewer
     // re-reads of an image's encoder rows; more tiles = more CUs pulling).  A head's bits do not depend on it.
@@ -863,13 +899,20 @@ struct Engine : EngineBase {
         const Lane& ln = lanes[li];
         const size_t r0 = ln.b0;
         const int H = cfg.dec_heads, HD = H * D;
-        {   // 1. x = LN(y) (residual), z = LN(x), q = z Wq^T
-            DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy + r0 * D; a.x_out = dx + r0 * D;
-            a.h_out = dqt + r0 * Id; a.F = Id;
+        const bool fold = dec_cross[l].wqp != nullptr;
+        if (fold) {   // 1+2. x = LN(y) (residual), z = LN(x), q' = z M^T  (M = 0.125 Wk_h^T Wq_h folded at load)
+            DecGemmArgs<T> a = base; a.N = HD; a.K = D; a.W = dec_cross[l].wqp; a.y = dy + r0 * D; a.x_out = dx + r0 * D;
+            a.h_out = dqp + r0 * HD; a.F = HD;
             if (int r = launch_dec_gemm<PRO_LN2, EPI_STORE_T>(s, a)) return r;
+        } else {
+            {   // 1. x = LN(y) (residual), z = LN(x), q = z Wq^T
+                DecGemmArgs<T> a = base; a.N = Id; a.K = D; a.W = dec_cross[l].wq; a.y = dy + r0 * D; a.x_out = dx + r0 * D;
+                a.h_out = dqt + r0 * Id; a.F = Id;
+                if (int r = launch_dec_gemm<PRO_LN2, EPI_STORE_T>(s, a)) return r;
+            }
+            // 2. q'_h = q_h (0.125 Wk_h)
+            launch_grp_gemm<DH>(s, dqt + r0 * Id, Id, dec_cross[l].wkT, dqp + r0 * HD, HD, ln.nb, HD, D);
         }
-        // 2. q'_h = q_h (0.125 Wk_h)
-        launch_grp_gemm<DH>(s, dqt + r0 * Id, Id, dec_cross[l].wkT, dqp + r0 * HD, HD, ln.nb, HD, D);
         {   // 3. c_h = softmax_n(q'_h . enc[n]) enc
             LatCoreArgs<T> a{};
             a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D;
@@ -893,6 +936,7 @@ struct Engine : EngineBase {
 #undef TXO_LA
             if (timed) ev_cross.push_back({e0, e1});
         }
+        if (fold) return 0;                                       // 4+5: the gated output projection takes c directly (K = heads*D, Wo' folded at load)
         // 4. o_h = c_h Wv_h^T ; 'b h n d -> b n (h d)'
         if (D == 64) launch_grp_gemm<64>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
         else if (D == 256) launch_grp_gemm<256>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
@@ -945,6 +989,7 @@ struct Engine : EngineBase {
                 dbg(s, "self out", l);
             }
             {   // cross attention (LN sandwich + q projection fused in): against the raw encoder rows (latent form) or over the cached projections
+                const bool fold = use_latent && dec_cross[l].wqp != nullptr;
                 if (use_latent) { if (int r = launch_lat_cross(s, li, l, bm ? bm->k : 1, base)) return r; }
                 else {
                 AttnOpt o; o.cross = true; o.W = dec_cross[l].wq; o.K = ckv + (size_t)(2 * l) * cross_stride;
@@ -955,6 +1000,7 @@ struct Engine : EngineBase {
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
                 g.resid = lx; g.y_out = ly;
+                if (fold) { g.K = cfg.dec_heads * D; g.W = dec_cross[l].wo_f; g.A = dcl + r0 * cfg.dec_heads * D; }
                 if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
                 dbg(s, "cross out", l);
             }
@@ -1336,6 +1382,7 @@ struct Engine : EngineBase {
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
         set_lanes(want, s);
+        last_ranges = n_lanes;
         reset_lanes(s, eos);
         bool use_graph = !eager && !prof && !prof_cross;   // event-carrying launches cannot be captured
         if (use_graph) for (int i = 0; i < n_lanes; ++i) if (int r = lane_graph(i, eos)) return r;
@@ -1506,6 +1553,8 @@ struct Engine : EngineBase {
     int query(int what, int64_t* out) override {
         if (what == TXO_Q_LAST_PERSISTENT) *out = last_persist ? 1 : 0;
         else if (what == TXO_Q_PERSIST_FALLBACKS) *out = persist_fallbacks;
+        else if (what == TXO_Q_LAST_ROW_RANGES) *out = last_persist ? 1 : last_ranges;
+        else if (what == TXO_Q_LAST_LATENT) *out = (!last_persist && use_latent) ? 1 : 0;
         else return fail(TXO_E_INVALID, "unknown query");
         return 0;
     }

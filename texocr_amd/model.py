@@ -184,7 +184,8 @@ class HipEngine:
         _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
 
     def query(self, what: int) -> int:
-        """txo_engine_query: 0 = the last generate() ran as one persistent launch, 1 = persistent launches that fell back."""
+        """txo_engine_query: 0 = the last generate() ran as one persistent launch, 1 = persistent launches that fell back,
+        2 = row ranges (streams) of the last launch-path decode, 3 = the last decode's cross attention ran in latent form."""
         out = C.c_int64(0)
         _lib.check(self.lib.txo_engine_query(self.handle, int(what), C.byref(out)))
         return out.value
