@@ -232,6 +232,14 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
                                                 "latent_form = B*N*D*s",
                            "kv_form_equivalent_GBps": round(algo_kv / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
                            "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n}
+        try:        # PMC bytes of the same whole-batch launch from the separate rocprofv3 passes of probes/profile_r04.sh (not measured in this run)
+            fn = os.path.join("profiles", f"r04_pmc_{dtype}_b{B}" + ("" if latent or dims.embed_dim != 256 else "_kvform") + ".json")
+            pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]
+            if pm["config"] == {"batch": B, "dtype": dtype, "tokens": N} and pm.get("rows_per_launch") == B and ("lat_core" in pm["kernel"]) == latent and dims.embed_dim == 256:
+                out["roofline"]["traffic"] = pm["traffic_bytes"]
+                out["roofline"]["traffic_source"] = fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
+        except Exception:
+            pass
     if want_encoder:
         eng.profile(True)
         m.generate(img, a.max_len)

@@ -8,7 +8,8 @@ dt=${1:-bf16}
 b=${2:-64}
 ml=${3:-24}
 tag=pmc_${dt}_b${b}
-if [ "$ml" != "24" ]; then export TXO_PERSIST=1; tag=pmc_persist_${dt}_b${b}; else export TXO_PERSIST=0; fi
+if [ "$ml" != "24" ]; then export TXO_PERSIST=1; tag=pmc_persist_${dt}_b${b}; else export TXO_PERSIST=0; export TXO_LANES=1; fi   # launches: ONE row range, a launch covers the whole batch
+[ -n "$TXO_PMC_TAG" ] && tag=${tag}_$TXO_PMC_TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/${tag}/$c -- \

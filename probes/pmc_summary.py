@@ -14,6 +14,11 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[r["Kernel_Name"].split("(")[0]][counter].append(float(r["Counter_Value"]))
 B, heads, N, esz = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), 8, 589, (2 if dtype == "bf16" else 4)
 max_len = int(sys.argv[4]) if len(sys.argv) > 4 else 24
+# rows ONE profiled launch covers: the profiled run decodes the batch as `ranges` row ranges (collect_pmc.sh runs with TXO_LANES=1, so
+# a launch covers the whole batch; r03's passes ran the two-range default and their 128-row launches were labelled with 256-row bytes)
+ranges = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+rows_per_launch = B // ranges
+D = 256
 kernels, cross, persist = {}, None, None
 for name, c in sorted(acc.items()):
     if "txo::" not in name:
@@ -21,7 +26,14 @@ for name, c in sorted(acc.items()):
     e = {"FETCH_SIZE_KB_avg": round(sum(c["FETCH_SIZE"]) / max(1, len(c["FETCH_SIZE"])), 1),
          "WRITE_SIZE_KB_avg": round(sum(c["WRITE_SIZE"]) / max(1, len(c["WRITE_SIZE"])), 1), "launches": len(c["FETCH_SIZE"])}
     if "dec_attn_kernel" in name and re.search(r"dec_attn_kernel<[^,]+, 0, 1, \d+,", name):   # cross attention (MODE 0, APRO_LN2, any NL)
-        e["algorithmic_bytes_per_launch"] = B * heads * 2 * N * 64 * esz
+        e["algorithmic_bytes_per_launch"] = rows_per_launch * heads * 2 * N * 64 * esz
+        e["rows_per_launch"] = rows_per_launch
+        e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
+        cross = (name, e)
+    if "lat_core_kernel" in name:                                          # cross attention in latent form: the raw encoder rows once for all heads
+        e["algorithmic_bytes_per_launch"] = rows_per_launch * N * D * esz
+        e["algorithmic_bytes_kv_form"] = rows_per_launch * heads * 2 * N * 64 * esz
+        e["rows_per_launch"] = rows_per_launch
         e["hbm_bytes_per_launch_corrected"] = int(2 * e["FETCH_SIZE_KB_avg"] * 1024 + e["WRITE_SIZE_KB_avg"] * 1024)
         cross = (name, e)
     if "decode_persist_kernel" in name:                                    # the whole decode loop as one launch
@@ -42,7 +54,8 @@ if persist is not None:
     sys.exit(0)
 out = {"note": "rocprofv3 --pmc <counter> --kernel-trace, separate passes (probes/collect_pmc.sh), bench.py --steps 1 --max-len 24 "
                f"(B={B}, {dtype}, 3x224x672). FETCH_SIZE/WRITE_SIZE are in KB; hbm_read_bytes = 2 * FETCH_SIZE * 1024 (gfx950 correction).",
-       "cross_attention_traffic": {"config": {"batch": B, "dtype": dtype, "tokens": N}, "kernel": cross[0],
-                                   "traffic_bytes": cross[1]["hbm_bytes_per_launch_corrected"]},
+       "cross_attention_traffic": {"config": {"batch": B, "dtype": dtype, "tokens": N}, "kernel": cross[0], "rows_per_launch": rows_per_launch,
+                                   "traffic_bytes": cross[1]["hbm_bytes_per_launch_corrected"],
+                                   "algorithmic_bytes": cross[1]["algorithmic_bytes_per_launch"]},
        "kernels": kernels}
 print(json.dumps(out, indent=1, sort_keys=True))
