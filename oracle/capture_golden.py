@@ -286,6 +286,30 @@ def cap_eos():
 
 
 @torch.no_grad()
+def cap_ragged():
+    """A padded multi-token start prefix with its mask (decoder.py:95-101,112; attention.py:130-155): decoder.generate(start_tokens
+    (B,T0), mask=(B,T0)) and decoder.net(x, mask=) from the reference -- left padding, an interior hole, and an all-True row."""
+    d, seed, img_seed = TINY, 17, 19
+    model, sd = build_reference(d, seed)
+    img = torch.from_numpy(synth.synth_images(3, 3, 32, 48, img_seed))
+    enc = model.encoder(img)
+    start = torch.tensor([[d.pad, d.pad, d.bos, 5, 9], [d.bos, 7, 3, 11, 2], [d.bos, 4, d.pad, 6, 8]], dtype=torch.long)
+    mask = torch.tensor([[0, 0, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 0, 1, 1]], dtype=torch.bool)
+    with greedy_patch() as gp:
+        toks = model.decoder.generate(start, eos_tok=None, max_len=12, enc=enc, mask=mask.clone())
+    step_logits = torch.stack(gp.logits, 1)
+    net = model.decoder.net(start, mask=mask.clone(), enc=enc)
+    # the same start tokens WITHOUT the mask must give other tokens somewhere (else the fixture pins nothing)
+    with greedy_patch():
+        plain = model.decoder.generate(start, eos_tok=None, max_len=12, enc=enc)
+    assert not torch.equal(plain, toks), "the mask changes nothing for these tokens: pick other start tokens"
+    save("ragged_prefix", {"dims": d.to_dict(), "weight_seed": seed, "image_seed": img_seed, "image_shape": [3, 3, 32, 48], "max_len": 12},
+         start=start.numpy().astype(np.int16), mask=mask.numpy(), tokens=toks.numpy().astype(np.int16),
+         step_logits=step_logits.numpy().astype(np.float32), margin=margins(step_logits), net_logits=net.numpy().astype(np.float32),
+         tokens_unmasked=plain.numpy().astype(np.int16))
+
+
+@torch.no_grad()
 def cap_window():
     """G9: sliding window (decoder.py:99-100): max_length=8 but max_len=20."""
     d = Dims(canvas=64, in_channels=3, embed_dim=64, enc_heads=2, enc_layers=1, dec_heads=2, dec_layers=1,
@@ -495,7 +519,7 @@ def cap_tokenizer():
     print("[golden] tokenizer_cases.json", len(cases), "cases")
 
 
-CAPS = {"cfg2_full": cap_cfg2_full, "cfg4_t64": cap_cfg4_t64, "tokenizer": cap_tokenizer, "cfg4": cap_cfg4, "wrapper": cap_wrapper, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
+CAPS = {"ragged": cap_ragged, "cfg2_full": cap_cfg2_full, "cfg4_t64": cap_cfg4_t64, "tokenizer": cap_tokenizer, "cfg4": cap_cfg4, "wrapper": cap_wrapper, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
         "window": cap_window, "sampling": cap_sampling}
 
 if __name__ == "__main__":

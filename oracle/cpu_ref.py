@@ -52,8 +52,11 @@ def _split_heads(t: torch.Tensor) -> torch.Tensor:
 
 
 def mha(sd: SD, p: str, xq: torch.Tensor, src: torch.Tensor, causal: bool,
-        kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
-    """MultiHeadAttention.forward with all-True padding masks (attention.py:101-180).
+        kv: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, q_mask: Optional[torch.Tensor] = None,
+        k_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MultiHeadAttention.forward (attention.py:101-180).  q_mask (B,nq) / k_mask (B,nk) bool: the reference's padding masks
+    (:130-155): energy[b,:,i,j] is filled with -FLT_MAX where not (q_mask[b,i] and k_mask[b,j]) -- a fully masked query row
+    therefore softmaxes uniformly over ALL keys.  None = all True.
 
     ``xq`` (B,nq,D) queries' input, ``src`` (B,nk,D) keys'/values' input (== xq for self
     attention, the raw encoder output for cross attention, attention.py:113-126).  If ``kv``
@@ -67,6 +70,11 @@ def mha(sd: SD, p: str, xq: torch.Tensor, src: torch.Tensor, causal: bool,
     else:
         k, v = kv
     energy = torch.matmul(q, k.transpose(-1, -2)) * SCALE                  # :148
+    if q_mask is not None or k_mask is not None:                           # :130-155
+        B_, nq_, nk_ = energy.shape[0], energy.shape[-2], energy.shape[-1]
+        qm = q_mask if q_mask is not None else torch.ones((B_, nq_), dtype=torch.bool)
+        km = k_mask if k_mask is not None else torch.ones((B_, nk_), dtype=torch.bool)
+        energy = energy.masked_fill(~(qm[:, None, :, None] & km[:, None, None, :]), -torch.finfo(energy.dtype).max)
     if causal:
         nq, nk = energy.shape[-2:]
         i = torch.arange(nq).view(nq, 1)
@@ -93,7 +101,7 @@ def ffn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
 
 
 def stack(sd: SD, prefix: str, kinds: List[str], x: torch.Tensor, enc: Optional[torch.Tensor],
-          causal: bool, trace: Optional[list] = None) -> torch.Tensor:
+          causal: bool, trace: Optional[list] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """AttentionLayers.forward (attention.py:223-269): ONE shared LayerNorm (:200,221), applied
     before every block and again after every residual add except the last (:242-259)."""
     g, b = sd[f"{prefix}.layers.0.0.weight"], sd[f"{prefix}.layers.0.0.bias"]
@@ -103,9 +111,9 @@ def stack(sd: SD, prefix: str, kinds: List[str], x: torch.Tensor, enc: Optional[
         r = x
         z = layer_norm(x, g, b)
         if kind == "self":
-            o = mha(sd, p, z, z, causal)
+            o = mha(sd, p, z, z, causal, q_mask=mask, k_mask=mask)        # attention.py:136-141: k_mask = q_mask for self attention
         elif kind == "cross":
-            o = mha(sd, p, z, enc, False)
+            o = mha(sd, p, z, enc, False, q_mask=mask)                    # ... and enc_mask (None -> all True) for cross attention
         else:
             o = ffn(sd, p, z)
         x = o + r
@@ -238,12 +246,13 @@ def encode(sd: SD, img: torch.Tensor, trace: Optional[list] = None, grid_w: Opti
 # --------------------------------------------------------------------------------------
 # decoder
 # --------------------------------------------------------------------------------------
-def decoder_net(sd: SD, tokens: torch.Tensor, enc: torch.Tensor, trace: Optional[list] = None) -> torch.Tensor:
-    """Transformer.forward with an all-True mask (decoder.py:41-67): logits for ALL positions."""
+def decoder_net(sd: SD, tokens: torch.Tensor, enc: torch.Tensor, trace: Optional[list] = None,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Transformer.forward (decoder.py:41-67): logits for ALL positions; mask (B,t) bool = its `mask` argument (None: all True)."""
     T = tokens.shape[1]
     x = sd["decoder.net.token_embedding.weight"][tokens]                    # :51
     x = x + sd["decoder.net.pos_embedding.embedding.weight"][:T][None]      # :52, attention.py:30-32
-    x = stack(sd, "decoder.net.attn_layers", kinds_of(sd, "decoder.net.attn_layers"), x, enc, True, trace)
+    x = stack(sd, "decoder.net.attn_layers", kinds_of(sd, "decoder.net.attn_layers"), x, enc, True, trace, mask=mask)
     x = layer_norm(x, sd["decoder.net.norm.weight"], sd["decoder.net.norm.bias"])   # :57
     return x @ sd["decoder.net.to_logits.weight"].t() + sd["decoder.net.to_logits.bias"]  # :60
 
@@ -264,25 +273,30 @@ def _all_rows_have_eos(output: torch.Tensor, eos: Optional[int]) -> bool:
 
 @torch.no_grad()
 def generate_recompute(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
-                       net_max_len: Optional[int] = None, collect_logits: bool = False, grid_w: Optional[int] = None):
+                       net_max_len: Optional[int] = None, collect_logits: bool = False, grid_w: Optional[int] = None,
+                       start_tokens: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
     """The reference algorithm as written: full-prefix recompute each step, cross K/V
     re-projected each step, sliding window (ocr_model.py:46-66, decoder.py:77-122), with the
     sampler replaced by argmax (greedy; argmax survives top-k and softmax(/temp))."""
     enc = encode(sd, img, grid_w=grid_w)
     B = img.shape[0]
     net_max_len = net_max_len or sd["decoder.net.pos_embedding.embedding.weight"].shape[0]
-    output = torch.full((B, 1), bos, dtype=torch.long)                      # ocr_model.py:57
+    output = torch.full((B, 1), bos, dtype=torch.long) if start_tokens is None else start_tokens.clone()   # ocr_model.py:57 / decoder.generate's start_tokens
+    T0 = output.shape[1]
+    m = torch.ones_like(output, dtype=torch.bool) if mask is None else mask.clone()                       # decoder.py:95
     steps = []
     for _ in range(max_len):                                                # decoder.py:97
         x = output[:, -net_max_len:]                                        # :99
-        logits = decoder_net(sd, x, enc)[:, -1, :]                          # :103
+        m = m[:, -net_max_len:]                                             # :100
+        logits = decoder_net(sd, x, enc, mask=None if mask is None else m)[:, -1, :]   # :103
+        m = F.pad(m, (0, 1), value=True)                                    # :112
         if collect_logits:
             steps.append(logits)
         nxt = logits.argmax(dim=-1, keepdim=True)
         output = torch.cat([output, nxt], dim=-1)                           # :111
         if _all_rows_have_eos(output, eos):                                 # :115
             break
-    toks = output[:, 1:]                                                    # :118
+    toks = output[:, T0:]                                                   # :118
     return (toks, torch.stack(steps, 1)) if collect_logits else toks
 
 

@@ -1435,3 +1435,30 @@ def test_eos_break_at_the_last_table_position_does_not_start_the_window(path, mo
     m.eos_token = None
     ref9 = cpu_ref.generate_recompute(sdt, img, d.bos, None, 9)
     assert np.array_equal(m.generate(img.cuda(), 9).cpu().numpy(), ref9.numpy())
+
+
+def test_ragged_start_prefix_with_padding_mask_matches_reference():
+    """A padded multi-token start prefix is a legal decoder.generate call (decoder.py:95-101,112; attention.py:130-155).  Fixture from the
+    reference: left padding, an interior hole, an all-True row.  decoder.generate(start_tokens, mask=) returns the reference's tokens;
+    decoder.net(x, mask=) its logits at every position that is not padding (rows of padded positions are unspecified: the reference
+    softmaxes them uniformly over all keys, nothing reads them); without the mask the tokens differ like the reference's do."""
+    meta, g = load_golden("ragged_prefix")
+    assert float(g["margin"].min()) >= 1e-4
+    d, sd, m = build(meta, max_batch=3)
+    img = images(meta).cuda()
+    enc = m.encoder(img)
+    start = torch.from_numpy(g["start"].astype(np.int64)).cuda()
+    mask = torch.from_numpy(g["mask"]).cuda()
+    toks = m.decoder.generate(start, None, meta["max_len"], enc=enc, mask=mask)
+    assert np.array_equal(toks.cpu().numpy(), g["tokens"])
+    net = m.decoder.net(start, mask=mask, enc=enc).cpu()
+    ref = torch.from_numpy(g["net_logits"])
+    keep = torch.from_numpy(g["mask"])
+    assert float((net - ref)[keep].abs().max()) < 1e-3
+    assert bool(torch.isfinite(net).all())
+    plain = m.decoder.generate(start, None, meta["max_len"], enc=enc)
+    assert np.array_equal(plain.cpu().numpy(), g["tokens_unmasked"])
+    # an all-True mask is the unmasked call; a 1-d start with a 1-d mask works like the reference's squeeze
+    assert torch.equal(m.decoder.generate(start, None, 6, enc=enc, mask=torch.ones_like(mask)), plain[:, :6])
+    one = m.decoder.generate(start[0], None, 6, enc=enc[:1], mask=mask[0])
+    assert one.shape == (6,) and np.array_equal(one.cpu().numpy(), g["tokens"][0, :6])

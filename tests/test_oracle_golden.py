@@ -243,3 +243,23 @@ def test_bf16_storage_alone_moves_the_random_hybrid_backbone_by_a_fifth():
     # one rounding alone is ~2^-9: the backbone amplifies it by well over an order of magnitude
     one = float((cpu_ref.bf16_round(e32) - e32).abs().mean() / e32.abs().mean())
     assert one < 0.004 and rel > 20 * one
+
+
+def test_ragged_prefix_mask_fixture():
+    """decoder.generate(start_tokens (B,T0), mask=) and decoder.net(x, mask=) of the reference (decoder.py:95-101,112; attention.py:130-155:
+    -FLT_MAX fill where query or key is padding, a fully masked query row softmaxes uniformly over all keys): the oracle reproduces
+    the captured tokens, every step's logits and net()'s logits at EVERY position, padded ones included."""
+    meta, g = load_golden("ragged_prefix")
+    d = Dims(**meta["dims"])
+    sd = cpu_ref.to_torch_sd(synth.synth_state_dict(d, meta["weight_seed"]))
+    img = torch.from_numpy(synth.synth_images(*meta["image_shape"], seed=meta["image_seed"]))
+    start = torch.from_numpy(g["start"].astype(np.int64))
+    mask = torch.from_numpy(g["mask"])
+    t, l = cpu_ref.generate_recompute(sd, img, d.bos, None, meta["max_len"], collect_logits=True, start_tokens=start, mask=mask)
+    assert np.array_equal(t.numpy(), g["tokens"])
+    assert float((l - torch.from_numpy(g["step_logits"])).abs().max()) < 1e-5
+    net = cpu_ref.decoder_net(sd, start, cpu_ref.encode(sd, img), mask=mask)
+    assert float((net - torch.from_numpy(g["net_logits"])).abs().max()) < 1e-5
+    # without the mask the same start tokens decode differently (the fixture pins something)
+    plain = cpu_ref.generate_recompute(sd, img, d.bos, None, meta["max_len"], start_tokens=start)
+    assert np.array_equal(plain.numpy(), g["tokens_unmasked"]) and not np.array_equal(plain.numpy(), g["tokens"])

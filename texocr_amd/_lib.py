@@ -32,6 +32,7 @@ SYMBOLS = {
     "txo_decode_begin": (C.c_int, [_P, _FP, _I, _I, _P]),
     "txo_decode_step": (C.c_int, [_P, _I64P, _I, _FP, _I64P, _P]),
     "txo_decode_prefill": (C.c_int, [_P, _I64P, _I, _FP, _P]),
+    "txo_decode_set_key_mask": (C.c_int, [_P, C.c_void_p, _I, _P]),
     "txo_generate": (C.c_int, [_P, _FP, _I, _I, _I, _I, _I, _I, _I64P, C.POINTER(C.c_int32), _FP, _P]),
     "txo_generate_from_enc": (C.c_int, [_P, _FP, _I, _I, _I, _I, _I64P, C.POINTER(C.c_int32), _FP, _P]),
     "txo_generate_beam": (C.c_int, [_P, _FP, _I, _I, _I, _I, _I, _I, _I, _I64P, _FP, _I64P, C.POINTER(C.c_int32), _P]),

@@ -53,6 +53,9 @@ template <typename T> struct DecAttnArgs {
     int kv_div;                     // cross: K/V image = row / kv_div (1 without beams)
     const short* path; int path_stride;   // self (APRO_NONE): null without beams
     unsigned long long* stamps;     // diagnostic (TXO_STAMPS): per block {entry, K panel consumed, exit}
+    // padding mask over the decoded positions (reference attention.py:130-155: energy filled with -FLT_MAX where the key is masked):
+    // kmask[row * kmask_stride + position] == 0 -> that position is never attended by a later query (KMASK instantiations only)
+    const unsigned char* kmask; int kmask_stride;
 };
 
 template <typename T, int PER16>
@@ -119,7 +122,7 @@ template <bool BEAM> struct DecAttnLds {
 // counter (tid < 64 of the workgroup's first group: a poll's wait would also wait for that wave's own panel) requests it
 // BEFORE the wait.  valid = false: same barriers, clamped addresses, no stores.
 // pf(): called once this tile's own loads have been issued (persistent kernel: requests the next stage's weights there).
-template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM, bool COH, class Wait, class Pf = NoPf>
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM, bool COH, class Wait, class Pf = NoPf, bool KMASK = false>
 __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, int tid, DecAttnLds<BEAM>& L_, bool valid,
                                               bool poll_wave, Wait&& wait_prev, Pf&& pf = NoPf{}) {
     constexpr int PER16 = Elem<T>::PER16;
@@ -382,7 +385,9 @@ __device__ __forceinline__ void dec_attn_tile(const DecAttnArgs<T>& a, int bh, i
             // the K registers of this slot are dead now: request the matching V rows into their place
             if constexpr (!V_EARLY) rv[u] = ld_kv(Vb + row_off(min(key, Lm1)) + sub * PER16);
             d = LPR == 8 ? row8_sum(d) : row16_sum(d);                         // all LPR lanes of the key get the dot
-            d = key < L ? d : -3.0e38f;
+            bool attend = key < L;
+            if constexpr (KMASK) attend = attend && a.kmask[(size_t)img * a.kmask_stride + min(key, a.lmax - 1)] != 0;
+            d = attend ? d : -3.0e38f;
             sc[u] = d;
             mx = fmaxf(mx, d);
             // keep the V requests in program order behind the K consumption (else both panels are live at once)
@@ -467,10 +472,10 @@ __device__ __forceinline__ void dec_attn_idle(int L, Wait&& wait_prev) {
     __syncthreads();                                                        // partial outputs
 }
 
-template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false>
+template <typename T, int MODE, int APRO, int NL, int WB, bool NARROW, bool BEAM = false, bool KMASK = false>
 __global__ __launch_bounds__(256, 2) void dec_attn_kernel(DecAttnArgs<T> a) {
     __shared__ DecAttnLds<BEAM> lds;
-    dec_attn_tile<T, MODE, APRO, NL, WB, NARROW, BEAM, false>(a, blockIdx.x, threadIdx.x, lds, true, false, NoWait{});
+    dec_attn_tile<T, MODE, APRO, NL, WB, NARROW, BEAM, false, NoWait, NoPf, KMASK>(a, blockIdx.x, threadIdx.x, lds, true, false, NoWait{});
 }
 
 }  // namespace txo

@@ -67,6 +67,7 @@ struct EngineBase {
     virtual int decode_begin(const float* enc, int B, int N, int eos, hipStream_t s) = 0;
     virtual int decode_step(const int64_t* tok_in, int t, float* logits_out, int64_t* tok_out, hipStream_t s) = 0;
     virtual int decode_prefill(const int64_t* tokens, int t, float* logits_out, hipStream_t s) = 0;
+    virtual int decode_set_key_mask(const unsigned char* mask, int cols, hipStream_t s) = 0;
     virtual int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                          int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) = 0;
     virtual int generate_beam(const float* img, const float* enc, int B, int C, int H, int W, int N, int beams, int max_len,
@@ -127,6 +128,7 @@ struct Engine : EngineBase {
     float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr, *dz = nullptr;
     T *dqt = nullptr, *dqp = nullptr, *dcl = nullptr;   // latent cross attention: q [B][inner], q' and c [B][heads*D] in the storage type
     int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
+    unsigned char* kmask = nullptr; bool kmask_on = false;   // padding mask over the decoded positions of a decode_step session (txo_decode_set_key_mask)
     // ----- decode session -----
     // A decode runs as 1..MAXL independent "lanes" (contiguous row ranges of the batch), each on its own HIP
     // stream with its own step state, so the latency chains of one lane's small kernels overlap the other's.
@@ -560,6 +562,7 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
+        if (int r = dalloc(&kmask, (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&done_flag, (size_t)Tmax * MAXL)) return r;
         if (int r = dalloc(&st, MAXL)) return r;
         if (int r = dalloc(&tok_buf, (size_t)Bmax * Tmax)) return r;
@@ -722,6 +725,7 @@ struct Engine : EngineBase {
         }
         sB = B; sN = N; sImg = B; session = true;
         ckv_valid = false;
+        kmask_on = false;
         // a session opened through the C entry point steps with launches: latent form only when forced
         use_latent = latent_ok && lat_mode == 1;
         if (!use_latent && project_kv) ensure_ckv(s);
@@ -839,6 +843,7 @@ struct Engine : EngineBase {
         a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
         a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t; a.t_host = step_host_t;
         a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path; a.path_stride = Tmax;
+        a.kmask = kmask + r0 * Tmax; a.kmask_stride = Tmax;
         a.stamps = (ln.nb * cfg.dec_heads <= STAMP_BLOCKS) ? next_stamp(o.cross ? "attn cross" : "attn self") : nullptr;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
         constexpr int NLS = sizeof(T) == 2 ? 8 : 16;       // self: 256 cached keys per pass
@@ -862,6 +867,10 @@ struct Engine : EngineBase {
         else if (o.apro == APRO_NONE && o.path) {
             if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, true, true>), grid, blk, 0, s, a);
             else hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, false, true>), grid, blk, 0, s, a);
+        }
+        else if (o.apro == APRO_NONE && kmask_on) {               // padding mask over the decoded positions (txo_decode_set_key_mask)
+            if (narrow) hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, true, false, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((dec_attn_kernel<T, ATT_SELF, APRO_NONE, NLS, 1, false, false, true>), grid, blk, 0, s, a);
         }
         else if (o.apro == APRO_NONE) TXO_DA(ATT_SELF, APRO_NONE, NLS, 1);
         else if (o.apro == APRO_EMBED) TXO_DA(ATT_SELF, APRO_EMBED, NLS, WBS);
@@ -966,7 +975,7 @@ struct Engine : EngineBase {
             {   // causal self attention
                 AttnOpt o; o.W = dec_self[l].wqkv; o.K = kc; o.V = vc; o.lmax = Tmax; o.x_out = lx;
                 if (bm) o.path = bm->path_cur;
-                if (self_plain || bm) {
+                if (self_plain || bm || kmask_on) {
                     // default: LN sandwich + QKV GEMM (weights read once per 16 rows; k/v appended to the cache by
                     // its epilogue), then the plain cached attention.  TXO_SELF_FUSED=1 folds the projection into
                     // the attention launch instead (same wall time at B=64; re-reads 96 KB of weights per image).
@@ -1102,7 +1111,24 @@ struct Engine : EngineBase {
         return 0;
     }
 
+    // Padding mask of decoder.generate / decoder.net (reference decoder.py:95-101,112; attention.py:130-155): mask [B][cols] bytes,
+    // 0 = the position is padding.  Its effect on every position that is NOT itself padding: padded positions are never attended by
+    // the causal self attention (energy filled with -FLT_MAX).  Rows of padded positions are computed but unspecified (the reference
+    // softmaxes them uniformly over all keys, future ones included; nothing reads them).  Applies to txo_decode_step of this session.
+    int decode_set_key_mask(const unsigned char* mask, int cols, hipStream_t s) override {
+        if (!session) return fail(TXO_E_STATE, "txo_decode_begin has not been called");
+        if (sImg != sB) return fail(TXO_E_STATE, "key masks are not available inside a beam-search session");
+        if (!mask) { kmask_on = false; return 0; }
+        if (cols < 1 || cols > Tmax) return fail(TXO_E_INVALID, "mask columns must be in [1, max_length]");
+        const int n = sB * Tmax;
+        hipLaunchKernelGGL(set_key_mask_kernel, dim3((n + 255) / 256), dim3(256), 0, s, mask, kmask, sB, cols, Tmax);
+        kmask_on = true;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
     int decode_prefill(const int64_t* tokens, int t, float* logits_out, hipStream_t s) override {
+        if (kmask_on) return fail(TXO_E_STATE, "txo_decode_prefill ignores padding masks: clear the key mask or step position by position");
         if (n_lanes != 1) return fail(TXO_E_STATE, "decode_prefill needs a session started by txo_decode_begin");
         if (sImg != sB) return fail(TXO_E_STATE, "decode_prefill is not available inside a beam-search session");
         lanes[0].stream = s;
@@ -1662,6 +1688,11 @@ int txo_decode_step(txo_engine* e, const int64_t* tok_in, int32_t t, float* logi
 int txo_decode_prefill(txo_engine* e, const int64_t* tokens, int32_t t, float* logits_out, void* stream) {
     if (!e || !tokens) return fail(TXO_E_INVALID, "null argument");
     return e->impl->decode_prefill(tokens, t, logits_out, (hipStream_t)stream);
+}
+
+int txo_decode_set_key_mask(txo_engine* e, const uint8_t* mask, int32_t cols, void* stream) {
+    if (!e) return fail(TXO_E_INVALID, "null engine");
+    return e->impl->decode_set_key_mask(mask, cols, (hipStream_t)stream);
 }
 
 int txo_generate(txo_engine* e, const float* img, int32_t B, int32_t C, int32_t H, int32_t W, int32_t max_len,

@@ -423,4 +423,12 @@ __global__ void cast_rows_kernel(const float* __restrict__ in, T* __restrict__ o
     }
 }
 
+// txo_decode_set_key_mask: the caller's (rows, cols) padding mask -> the engine's [rows][tmax] key mask (positions >= cols: attended)
+__global__ void set_key_mask_kernel(const unsigned char* __restrict__ mask, unsigned char* __restrict__ kmask, int rows, int cols, int tmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * tmax) return;
+    const int r = i / tmax, j = i - r * tmax;
+    kmask[i] = j < cols ? (mask[(size_t)r * cols + j] != 0 ? 1 : 0) : 1;
+}
+
 }  // namespace txo

@@ -142,6 +142,10 @@ class HipEngine:
         self._ensure()
         torch.ops.texocr.decode_begin(enc, self.id)
 
+    def set_key_mask(self, mask: Optional[torch.Tensor]) -> None:
+        """Padding mask (B, cols) bool over the positions of the current decode_step session (False = padding); None clears."""
+        torch.ops.texocr.decode_set_key_mask(mask, self.id)
+
     def decode_prefill(self, tokens: torch.Tensor, want_logits: bool = True) -> Optional[torch.Tensor]:
         """All positions of a prefix in one pass (txo_decode_prefill); the K/V cache then holds rows 0..t-1."""
         logits = torch.ops.texocr.decode_prefill(tokens, self.id, bool(want_logits))
@@ -281,15 +285,25 @@ class Transformer(nn.Module):
             raise ValueError(f"unsupported arguments for the inference path: {sorted(kw)}")
         if enc is None:
             raise ValueError("Must provide enc (cross-attending decoder)")       # attention.py:232-233
-        if mask is not None and not bool(mask.all()):
-            raise NotImplementedError("padding masks belong to the training forward (ocr_model.py:38-44), which is "
-                                      "outside the generate() path this engine accelerates")
+        padded = mask is not None and not bool(mask.all())
+        if padded and tuple(mask.shape) != tuple(x.shape):
+            raise ValueError("mask must have the shape of x")
         if x.ndim != 2 or x.dtype != torch.int64 or not x.is_cuda:
             raise ValueError("x must be an int64 GPU tensor of shape (B, t)")
         if x.shape[1] > self.max_len:
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
         eng.decode_begin(enc)
+        if padded:
+            # attention.py:130-155: a padded position is never attended by another query.  Logits AT padded positions are unspecified here
+            # (the reference softmaxes such a row uniformly over all keys, future ones included; nothing reads it): single-position steps
+            eng.set_key_mask(mask.to(x.device))
+            out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
+            xt = x.t().contiguous()
+            for t in range(x.shape[1]):
+                out[:, t] = eng.decode_step(t, xt[t])[0]
+            eng.set_key_mask(None)
+            return out
         # the one-pass prefill needs a vocabulary that is a multiple of 8 and a prefix that fits the engine's workspace
         # (max_batch * max_tokens rows); anything else takes the single-position steps
         if eng.dims.vocab % 8 == 0 and x.shape[1] <= eng.max_batch * eng.max_tokens and os.environ.get("TXO_NET_STEPWISE") is None:
@@ -326,8 +340,11 @@ class AutoRegressiveDecoder(nn.Module):
             raise ValueError(f"unsupported arguments: {sorted(kwargs)}")
         if enc is None:
             raise ValueError("Must provide enc (cross-attending decoder)")
-        if mask is not None and not bool(mask.all()):
-            raise NotImplementedError("a padding mask over the start tokens is not part of the generate() path")
+        if mask is not None and mask.ndim == 1:
+            mask = mask[None, :]
+        padded = mask is not None and not bool(mask.all())
+        if padded and tuple(mask.shape) != tuple(start_tokens.shape if start_tokens.ndim == 2 else start_tokens[None, :].shape):
+            raise ValueError("mask must have the shape of start_tokens")
         if decode not in ("greedy", "sample"):
             raise ValueError("decode must be 'greedy' or 'sample'")
         squeeze = start_tokens.ndim == 1
@@ -344,7 +361,11 @@ class AutoRegressiveDecoder(nn.Module):
             # beyond the positional table the engine slides the window with its multi-position forward, which needs a vocabulary
             # that is a multiple of 8 and a table that fits its workspace -- else the general stepwise loop below
             window_ok = max_len <= self.max_len or (eng.dims.vocab % 8 == 0 and self.max_len <= eng.max_batch * eng.max_tokens)
-            if T0 == 1 and bool((st == eng.dims.bos).all()) and (window_ok or return_logits):
+            if padded:
+                if return_logits:
+                    raise ValueError("return_logits is not available with a padding mask")
+                out = self._generate_stepwise(st, eos_tok, max_len, enc, mask=mask)
+            elif T0 == 1 and bool((st == eng.dims.bos).all()) and (window_ok or return_logits):
                 out = eng.generate(None, max_len, eos_tok, enc=enc, return_logits=return_logits)
             elif return_logits:
                 raise ValueError("return_logits needs a BOS start inside the positional table (max_len <= decoder.max_len)")
@@ -357,7 +378,7 @@ class AutoRegressiveDecoder(nn.Module):
             return (out[0].squeeze(0), out[1].squeeze(0)) if squeeze else out
         return out.squeeze(0) if squeeze else out
 
-    def _generate_stepwise(self, st, eos_tok, max_len, enc):
+    def _generate_stepwise(self, st, eos_tok, max_len, enc, mask=None):
         """General form (arbitrary start prefix, any max_len): one engine step per position with the reference's per-step
         host-side eos check (decoder.py:115-116); the engine picks the token (argmax or its sampler).
 
@@ -371,14 +392,20 @@ class AutoRegressiveDecoder(nn.Module):
         L = self.max_len
         eng.decode_begin(enc)
         output = st
+        # decoder.py:95-101,112: the mask covers the start tokens, every generated token extends it with True, and it slides with the window
+        m = None if mask is None else mask.to(device=enc.device, dtype=torch.bool)
+        if m is not None:
+            eng.set_key_mask(m[:, -L:])
         valid = 0                                                  # positions of the CURRENT window held by the cache
         for i in range(max_len):
             window = output[:, -L:]                                # decoder.py:99-100
             n = window.shape[1]
             if output.shape[1] > L:
                 valid = 0                                          # every position shifted: nothing cached is reusable
+                if m is not None:
+                    eng.set_key_mask(m[:, -L:])
             wt = window.t().contiguous()
-            if n - 1 - valid > 1 and eng.dims.vocab % 8 == 0:
+            if m is None and n - 1 - valid > 1 and eng.dims.vocab % 8 == 0 and n - 1 <= eng.max_batch * eng.max_tokens:
                 eng.decode_prefill(window[:, :n - 1].contiguous(), want_logits=False)   # positions 0..n-2 in one pass
             else:
                 for p in range(valid, n - 1):
@@ -390,8 +417,12 @@ class AutoRegressiveDecoder(nn.Module):
             _, tok = eng.decode_step(n - 1, wt[n - 1], want_logits=False)
             valid = n
             output = torch.cat((output, tok[:, None]), dim=-1)
+            if m is not None:
+                m = torch.nn.functional.pad(m, (0, 1), value=True)
             if eos_tok is not None and bool((output == eos_tok).any(dim=1).all()):
                 break
+        if m is not None:
+            eng.set_key_mask(None)
         return output[:, T0:]
 
 

@@ -112,6 +112,28 @@ def _(enc, engine):
     return None
 
 
+@custom_op("texocr::decode_set_key_mask", mutates_args=())
+def decode_set_key_mask(mask: Optional[torch.Tensor], engine: int) -> None:
+    """The `mask` argument of decoder.generate / decoder.net (decoder.py:95-101; attention.py:130-155) for the decode_step calls of
+    the current session: (B, cols) bool, False = padding (never attended by later queries); None clears it."""
+    e = _eng(engine)
+    B = getattr(e, "_B", None)
+    with torch.cuda.device(e.device):
+        if mask is None:
+            _lib.check(e.lib.txo_decode_set_key_mask(e.handle, None, 0, _stream()))
+            return
+        if mask.ndim != 2 or mask.shape[0] != B or not mask.is_cuda:
+            raise ValueError("mask must be a GPU tensor of shape (B, cols) matching the session started by texocr::decode_begin")
+        m8 = mask.to(torch.uint8).contiguous()
+        e._mask_keepalive = m8
+        _lib.check(e.lib.txo_decode_set_key_mask(e.handle, m8.data_ptr(), int(m8.shape[1]), _stream()))
+
+
+@decode_set_key_mask.register_fake
+def _(mask, engine):
+    return None
+
+
 @custom_op("texocr::decode_step", mutates_args=())
 def decode_step(tok_in: Optional[torch.Tensor], engine: int, t: int, batch: int, want_logits: bool) -> Tuple[torch.Tensor, torch.Tensor]:
     """One position: returns (logits (B, V) -- (0, V) when want_logits is false --, argmax token (B,))."""
