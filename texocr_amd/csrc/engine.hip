@@ -147,6 +147,12 @@ struct Engine : EngineBase {
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
+    // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
+    // measured +22 % for a plain 256x256 store epilogue at K = 768 (1.85 GB of output per launch), but the encoder's own epilogues
+    // (GeGLU halves the columns, the fp32 stream is read-modify-write) run the same with either policy: 45.84 vs 45.77 ms per ViT-Base
+    // encode (probes/enc_nt.py) -- so the default stays the plain store.
+    int enc_nt_env = getenv("TXO_ENC_NT") ? atoi(getenv("TXO_ENC_NT")) : 0;
+    int enc_nt(size_t) const { return enc_nt_env; }
     // cross attention in latent form (lat_attn.h): scores / values against the raw encoder rows instead of projected K/V panels.
     // latent_ok: the tile exists for this engine's width / storage type.  lat_mode (TXO_LATENT, read once): 1 = every decode runs with
     // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
@@ -684,26 +690,28 @@ struct Engine : EngineBase {
             // x is never written: the row kernel leaves {mean, rstd} of LN(y) per row (rows.h MODE 3) and the next GEMM epilogue
             // rebuilds its residual from y -- in place, ey is both its residual source and its output -- with the same expression.
             const ResidLN res_x{ey, estats, enc_gb, D}, res_first{ex, nullptr, nullptr, D};
+            // outputs far beyond the caches are written non-temporally (they would evict the GEMM's own operand panels from L2)
+            const int nt_y = enc_nt((size_t)M * D * 4), nt_qkv = enc_nt((size_t)3 * M * Ie * sizeof(T)), nt_h = enc_nt((size_t)M * Fe * sizeof(T));
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
             else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
             const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);
             if constexpr (sizeof(T) == 4) {
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
-                                   EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N});
+                                   EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N, nt_qkv});
                 hipLaunchKernelGGL((enc_attn_kernel<T>), agrid, dim3(256), 0, s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N,
                                    cfg.enc_heads);
             } else {                                              // perf mode: bf16 q/k/v, bf16 MFMA attention
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
-                                   EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N});
+                                   EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N, nt_qkv});
                 if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
                 else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
-                               EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo});
+                               EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo, nt_y});
             launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
-            gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe});
-            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2});
+            gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe, nt_h});
+            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2, nt_y});
         }
         launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M);
         if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }

@@ -49,15 +49,19 @@ template <typename T> struct LoadPatch {
 // The accumulator tile is staged through LDS and handed to the epilogue as 8 consecutive columns of one row
 // (plain: v[8] at columns n..n+7; paired: value v[8] and gate g[8] of outputs j..j+7), so every global access is a
 // 16- or 32-byte row segment instead of a 2-4 byte element of the MFMA register layout.
-template <typename TO> __device__ inline void store8(TO* p, const float (&v)[8]) {
+// nt: non-temporal stores.  The outputs of the encoder-side GEMMs are far larger than the caches and are next read by ANOTHER kernel; written
+// with the default policy they are allocated in L2 and push the GEMM's own operand panels out of it (probes/pp_store_policy.hip, 150 784 rows,
+// K = 768: 903-915 TFLOP/s with plain stores, 1094-1141 with non-temporal ones; K = 3072: no difference).  Wave-uniform flag.
+template <typename TO> __device__ inline void store8(TO* p, const float (&v)[8], int nt = 0) {
     if constexpr (sizeof(TO) == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+        if (nt) { __builtin_nontemporal_store(a, reinterpret_cast<f32x4*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<f32x4*>(p + 4)); }
+        else { *reinterpret_cast<f32x4*>(p) = a; *reinterpret_cast<f32x4*>(p + 4) = b; }
     } else {
         union { bf16 h[8]; u32x4 u; } c;
 #pragma unroll
         for (int e = 0; e < 8; ++e) c.h[e] = __float2bfloat16(v[e]);
-        st16(p, c.u);
+        if (nt) __builtin_nontemporal_store(c.u, reinterpret_cast<u32x4*>(p)); else st16(p, c.u);
     }
 }
 __device__ inline void load8(const float* p, float (&v)[8]) {
@@ -66,13 +70,13 @@ __device__ inline void load8(const float* p, float (&v)[8]) {
 }
 
 template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
-    T* out; int ldo; const float* bias;
+    T* out; int ldo; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         if (bias) { float b[8]; load8(bias + n, b);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += b[e]; }
-        store8<T>(out + (size_t)m * ldo + n, v);
+        store8<T>(out + (size_t)m * ldo + n, v, nt);
     }
     // split form (gemm_pp.h): column operands once per lane, row operands batched ahead of the arithmetic, masked store
     static constexpr bool HAS_ROW = false;
@@ -86,16 +90,16 @@ template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
     __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&)[10], bool valid) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += cb[e];
-        if (valid) store8<T>(out + (size_t)m * ldo + n, v);
+        if (valid) store8<T>(out + (size_t)m * ldo + n, v, nt);
     }
 };
 template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
-    T* base; size_t which_stride; int inner, heads, ntok;
+    T* base; size_t which_stride; int inner, heads, ntok; int nt = 0;
     static constexpr bool PAIRED = false;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
         const int b = m / ntok, t = m - b * ntok;
-        store8<T>(base + which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d, v);
+        store8<T>(base + which * which_stride + (((size_t)b * heads + head) * ntok + t) * DH + d, v, nt);
     }
     static constexpr bool HAS_ROW = false;
     __device__ inline void cols(int, float (&)[32]) const {}
@@ -125,13 +129,14 @@ struct ResidLN {
 template <bool FAST = false>                      // FAST: perf mode (bf16 operands), see common.h
 struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoid(g+bg) + resid[m][j..]   (fp32 stream)
     float* y; ResidLN res; const float* bias;     // bias is in the interleaved order
+    int nt = 0;
     static constexpr bool PAIRED = true;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8], r[10], cg[16];
         load8(bias + nv, bv); load8(bias + ng, bg); res.load(m, j, r); res.cols(j, cg);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * sigmoid_sel<FAST>(g[e] + bg[e]) + res.value(r, cg, e);
-        store8<float>(y + (size_t)m * res.D + j, v);
+        store8<float>(y + (size_t)m * res.D + j, v, nt);
     }
     static constexpr bool HAS_ROW = true;
     __device__ inline void cols(int nv, int ng, float (&cb)[32]) const {
@@ -143,18 +148,18 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
 #pragma unroll
         for (int e = 0; e < 8; ++e)
             v[e] = (v[e] + cb[e]) * sigmoid_sel<FAST>(g[e] + cb[8 + e]) + res.value(r, reinterpret_cast<const float (&)[16]>(cb[16]), e);
-        if (valid) store8<float>(y + (size_t)m * res.D + j, v);
+        if (valid) store8<float>(y + (size_t)m * res.D + j, v, nt);
     }
 };
 template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
-    T* h; const float* bias; int F;
+    T* h; const float* bias; int F; int nt = 0;
     static constexpr bool PAIRED = true;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8];
         load8(bias + nv, bv); load8(bias + ng, bg);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * gelu_sel<sizeof(T) == 2>(g[e] + bg[e]);
-        store8<T>(h + (size_t)m * F + j, v);
+        store8<T>(h + (size_t)m * F + j, v, nt);
     }
     static constexpr bool HAS_ROW = false;
     __device__ inline void cols(int nv, int ng, float (&cb)[32]) const {
@@ -164,18 +169,18 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
     __device__ inline void fin(int m, int j, float (&v)[8], const float (&g)[8], const float (&cb)[32], const float (&)[10], bool valid) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (v[e] + cb[e]) * gelu_sel<sizeof(T) == 2>(g[e] + cb[8 + e]);
-        if (valid) store8<T>(h + (size_t)m * F + j, v);
+        if (valid) store8<T>(h + (size_t)m * F + j, v, nt);
     }
 };
 struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
-    float* y; ResidLN res; const float* bias;
+    float* y; ResidLN res; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         float b[8], r[10], cg[16];
         load8(bias + n, b); res.load(m, n, r); res.cols(n, cg);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += b[e] + res.value(r, cg, e);
-        store8<float>(y + (size_t)m * res.D + n, v);
+        store8<float>(y + (size_t)m * res.D + n, v, nt);
     }
     static constexpr bool HAS_ROW = true;
     __device__ inline void cols(int n, float (&cb)[32]) const {
@@ -185,7 +190,7 @@ struct EpiBiasRes {                               // y[m][n..] = acc + bias + re
     __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&r)[10], bool valid) const {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += cb[e] + res.value(r, reinterpret_cast<const float (&)[16]>(cb[16]), e);
-        if (valid) store8<float>(y + (size_t)m * res.D + n, v);
+        if (valid) store8<float>(y + (size_t)m * res.D + n, v, nt);
     }
 };
 struct EpiPatch {                                 // x[b][1+p][n..] = acc + bias + pos[1 + pr*G + pc][n..]
