@@ -231,6 +231,13 @@ __device__ inline u32x4 ld16(const void* p) { return *reinterpret_cast<const u32
 // evicts the 18 MB of decoder weights from the 256 MB Infinity Cache on every step.
 __device__ inline u32x4 ld16_stream(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)); }
 __device__ inline void st16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+// experiment build (-DTXO_EXP_MALL=1): encoder-side streams that are dead after one use (the fp32 stream y read by the LayerNorm pass and by
+// the residual epilogues, q/k/v read by the attention) are requested non-temporally, so that the 231 MB bf16 operand the NEXT GEMM reads (z, the
+// attention output) survives in the 256 MB Infinity Cache
+#ifndef TXO_EXP_MALL
+#define TXO_EXP_MALL 0
+#endif
+__device__ inline u32x4 ld16_once(const void* p) { if constexpr (TXO_EXP_MALL) return ld16_stream(p); else return ld16(p); }
 
 // 16 bytes from an LDS BYTE ADDRESS (not a generic pointer: a ds_read_b128 for sure, never a flat load)
 __device__ inline float4 lds_ld_f4(unsigned addr) {

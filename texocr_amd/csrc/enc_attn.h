@@ -25,13 +25,26 @@ constexpr int EA_QBLK = 128, EA_KSTAGE = 64;
 
 __device__ inline int swz256(int row, int piece) { return row * 256 + ((piece ^ (row & 15)) << 4); }
 
+// Block -> (batch*head, query block).  One-dimensional grid of 8 * ceil(nbh / 8) * nq workgroups: workgroups b and b + 8 run on one XCD
+// (round-robin dispatch), so the nq query blocks of ONE (image, head) go to ONE XCD and its L2 fetches that head's K / V panel once for
+// all of them.  (With the (query block, batch*head) grid the five query blocks of a head landed on five XCDs: every K / V panel crossed
+// the fabric five times -- 2.3 GB per ViT-Base layer in 0.44 ms, i.e. the attention kernel was at the fabric's rate, not the VALU's.)
+__device__ inline bool ea_block(int nq, int nbh, int& bh, int& qb) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    bh = (slot / nq) * 8 + xcd; qb = slot - (slot / nq) * nq;
+    return bh < nbh;
+}
+inline dim3 ea_grid(int nq, int nbh) { return dim3(((nbh + 7) / 8) * 8 * nq); }
+
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__ Q, const float* __restrict__ Kg,
                                                        const float* __restrict__ Vg, TO* __restrict__ out, int N,
-                                                       int heads) {
+                                                       int heads, int nbh) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 256];   // [buf][K|V]
-    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * EA_QBLK;
+    int bh, qblk;
+    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk)) return;
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = qblk * EA_QBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lg = lane >> 4;
     const float* Qb = Q + (size_t)bh * N * DH;
@@ -208,11 +221,13 @@ constexpr float EAB_GROW = 6.0f;      // base-2 units: P stays below 64 between 
 
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
-                                                            const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads) {
+                                                            const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads, int nbh) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][EA_KSTAGE * 128 + DH * EAB_VT_STRIDE];   // [buf]{K | Vt}
     static_assert(2 * (EA_KSTAGE * 128 + DH * EAB_VT_STRIDE) >= 4 * 32 * 64 * 4, "epilogue tile must fit");
-    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * EA_QBLK;
+    int bh, qblk;
+    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk)) return;
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = qblk * EA_QBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lg = lane >> 4;
     const bf16* Qb = Q + (size_t)bh * N * DH;
@@ -405,12 +420,14 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
 // q,k,v: bf16 head-major [B*heads][N][64].  Bound: MFMA bf16 / softmax VALU, about equal.
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
-                                                               const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads) {
+                                                               const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads, int nbh) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 128];   // [buf][K | V], 128-byte rows
     static_assert(sizeof(lds) >= 4 * 32 * 64 * 4, "epilogue tile must fit");
     typedef short s16x4 __attribute__((ext_vector_type(4)));
-    const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
-    const int q0 = blockIdx.x * EA_QBLK;
+    int bh, qblk;
+    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk)) return;
+    const int b = bh / heads, head = bh - b * heads;
+    const int q0 = qblk * EA_QBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lc = lane & 15, lg = lane >> 4;
     const bf16* Qb = Q + (size_t)bh * N * DH;
@@ -424,7 +441,7 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
         const int qrow = min(q0 + wave * 32 + qt * 16 + lc, N - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const u32x4 raw = ld16(Qb + (size_t)qrow * DH + ks * 32 + lg * 8);
+            const u32x4 raw = ld16_once(Qb + (size_t)qrow * DH + ks * 32 + lg * 8);
             const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
             unsigned o[4];
 #pragma unroll
@@ -448,8 +465,8 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
             const int key = min(s * EA_KSTAGE + row, N - 1);
-            rk[i] = ld16(Kb + (size_t)key * DH + piece * 8);
-            rv[i] = ld16(Vb + (size_t)key * DH + piece * 8);
+            rk[i] = ld16_once(Kb + (size_t)key * DH + piece * 8);
+            rv[i] = ld16_once(Vb + (size_t)key * DH + piece * 8);
         }
     };
     auto store_stage = [&](int buf) {

@@ -694,18 +694,19 @@ struct Engine : EngineBase {
             const int nt_y = enc_nt((size_t)M * D * 4), nt_qkv = enc_nt((size_t)3 * M * Ie * sizeof(T)), nt_h = enc_nt((size_t)M * Fe * sizeof(T));
             if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
             else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
-            const dim3 agrid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);
+            const dim3 agrid = ea_grid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);   // XCD-aware block order (enc_attn.h: ea_block)
+            const int nbh = B * cfg.enc_heads;
             if constexpr (sizeof(T) == 4) {
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<float>{eqkv, hs, Ie, cfg.enc_heads, N, nt_qkv});
                 hipLaunchKernelGGL((enc_attn_kernel<T>), agrid, dim3(256), 0, s, eqkv, eqkv + hs, eqkv + 2 * hs, eao, N,
-                                   cfg.enc_heads);
+                                   cfg.enc_heads, nbh);
             } else {                                              // perf mode: bf16 q/k/v, bf16 MFMA attention
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N, nt_qkv});
-                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
-                else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads);
+                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh);
+                else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh);
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
                                EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo, nt_y});

@@ -115,7 +115,11 @@ template <typename T> struct EpiHeads {           // scatter n = (which, head, d
 struct ResidLN {
     const float* resid; const float* stats; const float* gb; int D;     // gb: gamma[D] followed by beta[D]
     __device__ inline void load(int m, int j, float (&r)[10]) const {
-        load8(resid + (size_t)m * D + j, reinterpret_cast<float (&)[8]>(r));
+        {   // the fp32 stream: read once per sub-layer (see common.h: ld16_once)
+            const u32x4 a = ld16_once(resid + (size_t)m * D + j), b = ld16_once(resid + (size_t)m * D + j + 4);
+            r[0] = __uint_as_float(a.x); r[1] = __uint_as_float(a.y); r[2] = __uint_as_float(a.z); r[3] = __uint_as_float(a.w);
+            r[4] = __uint_as_float(b.x); r[5] = __uint_as_float(b.y); r[6] = __uint_as_float(b.z); r[7] = __uint_as_float(b.w);
+        }
         if (stats) { const float2 st = *reinterpret_cast<const float2*>(stats + (size_t)m * 2); r[8] = st.x; r[9] = st.y; }
     }
     // cg: gamma[j..j+7], beta[j..j+7] (loaded once per lane by cols())

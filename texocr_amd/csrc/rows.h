@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        v[i] = *reinterpret_cast<const float4*>(in + (size_t)row * D + c);
+        v[i] = __builtin_bit_cast(float4, MODE == 3 ? ld16_once(in + (size_t)row * D + c) : ld16(in + (size_t)row * D + c));
         g[i] = *reinterpret_cast<const float4*>(gamma + c);
         b[i] = *reinterpret_cast<const float4*>(beta + c);
     }
