@@ -935,7 +935,8 @@ struct Engine : EngineBase {
             LatCoreArgs<T> a{};
             a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D;
             a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = sN; a.kv_div = kv_div;
-            const int nblk = ((ln.nb + 7) / 8) * 8 * a.ngrp;       // XCD-aware tile order (lat_core_kernel)
+            const int nimg = (ln.nb + kv_div - 1) / kv_div;
+            const int nblk = ((nimg + 7) / 8) * 8 * kv_div * a.ngrp;   // XCD-aware tile order (lat_core_kernel)
             a.stamps = (nblk <= STAMP_BLOCKS) ? next_stamp("attn cross (latent core)") : nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());

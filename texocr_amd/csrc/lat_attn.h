@@ -292,10 +292,12 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
 template <typename T, int D_>
 __global__ __launch_bounds__(la_waves<D_>() * 64) void lat_core_kernel(LatCoreArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char la_smem[];
-    // workgroups b and b + 8 run on one XCD (round-robin dispatch): the head groups of ONE row go to ONE XCD, whose L2 then
-    // fetches the image's encoder rows once for all of them (row = (slot / ngrp) * 8 + xcd, head group = slot % ngrp)
+    // workgroups b and b + 8 run on one XCD (round-robin dispatch): every tile that reads ONE image's encoder rows -- its head groups, and in
+    // a beam search its kv_div beams -- goes to ONE XCD, whose L2 then fetches those rows once for all of them
+    // (image = (slot / tpu) * 8 + xcd, tile within the image = slot % tpu: row = image * kv_div + w / ngrp, head group = w % ngrp)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int row = (slot / a.ngrp) * 8 + xcd, hg = slot - (slot / a.ngrp) * a.ngrp;
+    const int tpu = a.kv_div * a.ngrp, unit = (slot / tpu) * 8 + xcd, w = slot - (slot / tpu) * tpu;
+    const int row = unit * a.kv_div + w / a.ngrp, hg = w - (w / a.ngrp) * a.ngrp;
     if (row >= a.rows) return;
     lat_core_tile<T, D_>(a, row * a.ngrp + hg, threadIdx.x, la_smem);
 }
