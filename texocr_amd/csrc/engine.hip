@@ -1415,6 +1415,9 @@ struct Engine : EngineBase {
         // (also the narrow decoder's bf16 greedy decode beyond the persistent launch's range, see persist_usable)
         int want = (sizeof(T) == 2 && !sample_mode && !prof && !prof_cross &&       // (profiling times whole-batch launches)
                     ((D >= 512 && B >= 256) || (D < 512 && B > PERSIST_MAX_BF16_GREEDY))) ? 2 : 1;
+        // in latent form the second range pays from ~224 rows on (160: 66.6 ms with one range vs 71.7 with two, 192: 70.6 vs 72.2, 256: 82.0 vs 77.9;
+        // K/V form: two ranges from 129 on, 160: 70.9 vs 66.3)
+        if (want == 2 && use_latent && D < 512 && B < 224) want = 1;
         if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
         if (B < 32) want = 1;
         set_lanes(want, s);
