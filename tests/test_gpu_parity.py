@@ -1262,6 +1262,9 @@ def test_latent_cross_attention_matches_kv_form_fp32(shape):
         m.eos_token = None
         toks, logits = m.generate(img, T, return_logits=True)
         assert m._engine.query(0) == (0 if latent else m._engine.query(0))       # forced latent form decodes with launches
+        assert m._engine.query(3) == latent
+        if latent:
+            assert torch.equal(m.generate(img, T), toks)      # without logits: up to 4 images replay a captured graph of the same launches
         outs.append((toks.cpu(), logits.cpu()))
         del m
     (t0, l0), (t1, l1) = outs
