@@ -935,8 +935,14 @@ struct Engine : EngineBase {
             LatCoreArgs<T> a{};
             a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D;
             a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = sN; a.kv_div = kv_div;
-            const int nimg = (ln.nb + kv_div - 1) / kv_div;
-            const int nblk = ((nimg + 7) / 8) * 8 * kv_div * a.ngrp;   // XCD-aware tile order (lat_core_kernel)
+            int nimg = (ln.nb + kv_div - 1) / kv_div;
+            if (kv_div > 1 && ln.nb % kv_div == 0 && lat_g_env == 0) {
+                // beam search: the k beams of an image read the SAME encoder rows, and their q' / c rows are contiguous ([rows][heads * D]) --
+                // one image = ONE row of k * heads heads, LA_GMAX of them per tile (the MFMA tile has 16 head columns whether 8 or 16 are
+                // used): 640 tiles of 8 heads become 384 of up to 16.  A head's bits do not depend on the grouping.
+                a.rows = nimg; a.heads = H * kv_div; a.G = LA_GMAX; a.ngrp = (a.heads + LA_GMAX - 1) / LA_GMAX; a.kv_div = 1;
+            }
+            const int nblk = ((nimg + 7) / 8) * 8 * a.kv_div * a.ngrp;   // XCD-aware tile order (lat_core_kernel)
             a.stamps = (nblk <= STAMP_BLOCKS) ? next_stamp("attn cross (latent core)") : nullptr;
             hipEvent_t e0 = nullptr, e1 = nullptr;
             const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());
