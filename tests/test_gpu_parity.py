@@ -667,11 +667,13 @@ def test_custom_ops_and_module_state_dict():
     assert bool((m2.generate(img, 4) == 5).all())
 
 
-def test_beam_search_extension():
+@pytest.mark.parametrize("vocab", [1000, 1100], ids=["rows_in_registers", "general_path"])
+def test_beam_search_extension(vocab):
     """BASELINE config 5 asks for beam search; the reference has none, so parity is anchored at
-    beams=1 == greedy, plus agreement with the oracle's independent CPU restatement of the same definition."""
+    beams=1 == greedy, plus agreement with the oracle's independent CPU restatement of the same definition.
+    Both forms of beam_select_kernel (csrc/step.h): an image's k rows in registers up to 1024 entries, the general path beyond."""
     cpu_ref = _oracle()
-    d = Dims(canvas=224)
+    d = Dims(canvas=224, vocab=vocab)
     d, sd, m = build(d, seed=0, max_batch=12)
     img = torch.from_numpy(synth.synth_images(3, 3, 64, 96, seed=41))
     m.eos_token = None

@@ -308,6 +308,110 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k = a.k, V = a.V, t = a.st->t;
     const float* lg = a.logits + (size_t)img * k * V;
+    constexpr int VPT = 4;                                    // register path: vocabularies up to 256 * VPT entries
+    if (V <= 256 * VPT) {
+        // The image's k rows live in registers (thread tid holds entries tid + 256 i of every row): ONE read of the logits, the k
+        // log-sum-exps reduced together (two barriers instead of three per beam), k selection rounds over registers (one barrier
+        // each).  Same per-thread summation order, same wave / block reductions and the same tie rule as the general path below
+        // -> the same bits (it measured 50 us per position at 128 images x 5 beams x 1000 entries against 640 rows' decode step).
+        __shared__ float rmx[KMAX][4], rse[KMAX][4], rbv[2][4];
+        __shared__ int rbi[2][4];
+        float x[KMAX][VPT], sc[KMAX]; int fn[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            sc[j] = 0.f; fn[j] = 0;
+            if (j < k) { sc[j] = a.score[img * k + j]; fn[j] = a.fin[img * k + j]; }
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) { const int v = tid + 256 * i; x[j][i] = (j < k && v < V) ? lg[(size_t)j * V + v] : 0.f; }
+        }
+        float mx[KMAX], lse[KMAX];
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) if (j < k) {
+            float m = -3.4e38f;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) if (tid + 256 * i < V) m = fmaxf(m, x[j][i]);
+            m = wave_max(m);
+            if (lane == 0) rmx[j][wave] = m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) if (j < k) {
+            mx[j] = fmaxf(fmaxf(rmx[j][0], rmx[j][1]), fmaxf(rmx[j][2], rmx[j][3]));
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) if (tid + 256 * i < V) se += expf(x[j][i] - mx[j]);
+            se = wave_sum(se);
+            if (lane == 0) rse[j][wave] = se;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) if (j < k) lse[j] = mx[j] + logf((rse[j][0] + rse[j][1]) + (rse[j][2] + rse[j][3]));
+        // candidates in place of the logits
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) if (j < k) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) {
+                const int v = tid + 256 * i;
+                if (fn[j]) x[j][i] = (v == a.eos) ? sc[j] : -INFINITY;
+                else x[j][i] = sc[j] + (x[j][i] - lse[j]);
+            }
+        }
+        unsigned taken = 0u;                                  // bit j * VPT + i: this thread's candidate was selected in an earlier round
+        float sv[KMAX]; int si[KMAX];
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) if (r < k) {
+            float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) if (j < k) {
+#pragma unroll
+                for (int i = 0; i < VPT; ++i) {
+                    const int v = tid + 256 * i, f = j * V + v;
+                    if (v >= V || ((taken >> (j * VPT + i)) & 1u)) continue;
+                    const float c = x[j][i];
+                    if (c > best || (c == best && f < bi)) { best = c; bi = f; }
+                }
+            }
+            wave_argmax(best, bi);
+            if (lane == 0) { rbv[r & 1][wave] = best; rbi[r & 1][wave] = bi; }
+            __syncthreads();
+            float b = rbv[r & 1][0]; int ix = rbi[r & 1][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) { const float bw = rbv[r & 1][w]; const int iw = rbi[r & 1][w]; if (bw > b || (bw == b && iw < ix)) { b = bw; ix = iw; } }
+            sv[r] = b; si[r] = ix;
+            const int j = ix / V, v = ix - j * V;
+            if ((v & 255) == tid) taken |= 1u << (j * VPT + (v >> 8));
+        }
+        int allfin = 1;
+#pragma unroll
+        for (int r = 0; r < KMAX; ++r) if (r < k) {
+            const int j = si[r] / V, v = si[r] - j * V;
+            int fj = 0;
+#pragma unroll
+            for (int q = 0; q < KMAX; ++q) if (q == j) fj = fn[q];
+            const int nf = fj | ((a.eos >= 0 && v == a.eos) ? 1 : 0);
+            allfin &= nf;
+            if (tid == r) {
+                const int row = img * k + r;
+                a.score[row] = sv[r]; a.fin[row] = nf; a.cur_tok[row] = v;
+                a.tok_hist[(size_t)t * a.hist_stride + row] = v;
+                a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(img * k + j);
+            }
+            const short* src = a.path_cur + (size_t)(img * k + j) * a.path_stride;
+            short* dst = a.path_nxt + (size_t)(img * k + r) * a.path_stride;
+            for (int p2 = tid; p2 < t; p2 += 256) dst[p2] = src[p2];
+            if (tid == 0) dst[t] = (short)(img * k + j);
+        }
+        if (tid == 0) {
+            const unsigned add = 1u + ((a.eos >= 0 && allfin) ? (1u << 16) : 0u);
+            const unsigned old = atomicAdd(&a.st->arrive, add);
+            if ((old & 0xffffu) == (unsigned)(a.images - 1)) {
+                a.done_flag[t] = (int)((old + add) >> 16) >= a.images ? 1 : 0;
+                a.st->arrive = 0u;
+                a.st->t = t + 1;
+            }
+        }
+        return;
+    }
     if (tid < k) { s_score[tid] = a.score[img * k + tid]; s_fin[tid] = a.fin[img * k + tid]; }
     // log-sum-exp of every beam's row
     for (int j = 0; j < k; ++j) {
