@@ -828,6 +828,32 @@ def test_wide_decoder_large_batch_ffn_path():
     assert a1 > 0.99                                # measured 0.998
 
 
+def test_folded_out_projection_on_32_row_blocks_bit_identical_to_16_row_blocks():
+    """From 512 decode rows on (a beam search's rows), the latent form's folded output projection (K = heads * D = 2048) runs on
+    32-row blocks that share their weight fragments (dec_gemm_wide_kernel<EPI_GLU_RES, 16, 32, 2>): same K split, same reduction
+    order, same epilogue as the 16-row tile -> the same bits.  520 rows on ONE row range against the engine with that routing off."""
+    import os
+    d = Dims(canvas=224, max_len=16)
+    img = torch.from_numpy(synth.synth_images(520, 3, 32, 64, seed=91)).cuda()
+    outs = []
+    for off in (False, True):
+        if off: os.environ["TXO_DEC_WIDE_OFF"] = "1"
+        try:
+            _, _, m = build(d, seed=5, dtype="bf16", max_batch=520)
+        finally:
+            os.environ.pop("TXO_DEC_WIDE_OFF", None)
+        m.eos_token = None
+        os.environ["TXO_LANES"] = "1"
+        try:
+            outs.append(m.generate(img, 12, return_logits=True))
+        finally:
+            os.environ.pop("TXO_LANES")
+        assert m._engine.query(0) == 0 and m._engine.query(3) == 1          # launches, latent form
+        del m
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])                                # logits bit for bit
+
+
 # ------------------------------------------------------------------------------------------------
 # the decode loop as ONE persistent launch (csrc/persist.h) against the launch-per-stage path
 # ------------------------------------------------------------------------------------------------

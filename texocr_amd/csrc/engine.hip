@@ -820,9 +820,12 @@ struct Engine : EngineBase {
     bool launch_dec_gemm_wide(hipStream_t s, DecGemmArgs<T> a) {
         if constexpr (sizeof(T) != 2) { (void)s; (void)a; return false; }
         else {
-            if (a.rows < 128 || D < 512 || dec_wide_off) return false;
+            if (a.rows < 128 || dec_wide_off) return false;
             constexpr int KCH = Elem<T>::KCHUNK;
             const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
+            // narrow decoder: only the folded latent output projection (K = heads * D = 2048) of a beam search's many rows -- 640 rows are
+            // 1280 16-row blocks of 128 KB each (19.6 us); at 256 rows the 32-row blocks are too few to fill the chip (measured slower)
+            if (D < 512 && !(kw == 16 && a.rows >= 512 && EPI == EPI_GLU_RES)) return false;
             a.stamps = nullptr;
 #define TXO_DGW(KW_, BN_, RT_)                                                                                              \
             do {                                                                                                            \
@@ -831,6 +834,7 @@ struct Engine : EngineBase {
                 return true;                                                                                                \
             } while (0)
             if (kw == 6) TXO_DGW(6, 32, 4);                  // K = 768: the gated out-projections, FFN-in behind its LayerNorm launch
+            if constexpr (EPI == EPI_GLU_RES) { if (kw == 16) TXO_DGW(16, 32, 2); }
 #undef TXO_DGW
             return false;
         }
