@@ -14,7 +14,7 @@ Objects on the line besides the contract's fields:
                   `traffic` = PMC bytes per launch from a separate rocprofv3 pass (file named in `traffic_source`).
   cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") on this host: `value` = recompute mode = the reference's
                   algorithm (no KV cache, decoder.py:97-103) on a bounded sample; `cached` = the same oracle with a KV cache.
-  fp32_parity_mode, sampled_decode, b256, cfg4 (N=1 only, after the timed region; --no-extras skips them):
+  fp32_parity_mode, sampled_decode, b256, cfg4, cfg5_beam (N=1 only, after the timed region; --no-extras skips them):
                   the token-exact fp32 engine on the same workload; the reference's default (sampled) decode; batch 256 (the north-star HBM target: cross-attention
                   >= 50 % of 8 TB/s); BASELINE configs[3] (ViT-Base 12L/768d + 6L decoder, B=256: encoder >= 40 % of the
                   bf16 MFMA peak).
@@ -181,6 +181,37 @@ def enc_flop(dims, B, N):
     """encoder (patch-embed + ViT stack) FLOPs, SURVEY 8d: 2(N-1)C*256*D + Le*(N(10DI + 6DF) + 4N^2 I) per image"""
     D_, I_, F_, Le = dims.embed_dim, dims.enc_inner, dims.enc_ffn, dims.enc_layers
     return B * (2 * (N - 1) * dims.in_channels * 256 * D_ + Le * (N * (10 * D_ * I_ + 6 * D_ * F_) + 4 * N * N * I_))
+
+
+def beam_measurement(dtype, a, dev, B=128, k=5, widths=(224, 448, 672, 896)):
+    """BASELINE configs[4] on one GPU: beam search k=5 (a build extension: the reference has none) over 128 images per
+    width bucket, widths 224..896, max_len as the headline; images/s over the four buckets together."""
+    import torch
+    from texocr_amd import synth
+    from texocr_amd.config import Dims
+    from texocr_amd.model import model_from_dims
+    d = Dims(canvas=max(widths))
+    m = model_from_dims(d, dtype=dtype, max_batch=B * k, max_tokens=d.n_tokens(224, max(widths)))
+    m.load_state_dict(synth.synth_state_dict(d, 0))
+    m.eos_token = None                                    # every position runs
+    g = torch.Generator(device=dev).manual_seed(977)
+    per, tot = {}, 0.0
+    for W in widths:
+        img = torch.rand((B, d.in_channels, 224, W), generator=g, device=dev, dtype=torch.float32)
+        m.generate(img, 16, beam=k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.generate(img, a.max_len, beam=k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per[f"224x{W}"] = round(B / dt, 1)
+        tot += dt
+    out = {"value": round(B * len(widths) / tot, 1), "unit": "images/sec", "beams": k, "images_per_bucket": B, "images_per_sec_by_width": per,
+           "dtype": dtype, "max_len": a.max_len,
+           "workload": "BASELINE configs[4] on ONE GPU: beam search k=5, 128 images per width bucket, widths 224..896 (bucketed by exact size)"}
+    del m
+    torch.cuda.empty_cache()
+    return out
 
 
 def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encoder, sampled=False):
@@ -447,6 +478,7 @@ def main():
                 d4 = Dims(canvas=max(a.height, a.width), embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6)
                 result["cfg4"] = side_measurement(d4, a.dtype, 256, a, dev, 1, 3, True, True)
                 result["cfg4"]["workload"] = "BASELINE configs[3]: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h), batch 256"
+                result["cfg5_beam"] = beam_measurement(a.dtype, a, dev)
             except Exception as e:                          # a side measurement must never lose the headline line
                 result["extras_error"] = f"{type(e).__name__}: {e}"
         if not a.no_cpu_baseline and world == 1:            # reported at N=1 only (bench contract)
