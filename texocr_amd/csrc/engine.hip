@@ -147,6 +147,7 @@ struct Engine : EngineBase {
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
+    bool kw24_off = getenv("TXO_KW24_OFF") != nullptr;    // experiment switch: FFN-out at K = 3072 on the run-time-K tile (three request groups) instead of the fixed one
     // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
     // measured +22 % for a plain 256x256 store epilogue at K = 768 (1.85 GB of output per launch), but the encoder's own epilogues
     // (GeGLU halves the columns, the fp32 stream is read-modify-write) run the same with either policy: 45.84 vs 45.77 ms per ViT-Base
@@ -798,7 +799,11 @@ struct Engine : EngineBase {
             if (half) {
                 switch (kw) {
                     case 4: TXO_DG(4, 16); break;    case 6: TXO_DG(6, 16); break;    case 8: TXO_DG(8, 16); break;
-                    case 12: TXO_DG(12, 16); break;  case 16: TXO_DG(16, 16); break;  default: TXO_DG(0, 16);
+                    case 12: TXO_DG(12, 16); break;  case 16: TXO_DG(16, 16); break;
+                    case 24:                                 // K = 3072 (FFN-out of a 768-wide decoder): every fragment requested up front, one round trip instead of three
+                        if constexpr (EPI == EPI_BIAS_RES && sizeof(T) == 2) { if (!kw24_off) { TXO_DG(24, 16); break; } }
+                        TXO_DG(0, 16); break;
+                    default: TXO_DG(0, 16);
                 }
             } else {
                 TXO_DG(0, 32);
