@@ -692,10 +692,38 @@ def test_beam_search_extension(vocab):
         best = m.generate(img.cuda(), 24, beam=k)
         assert torch.equal(best, toks[:, 0])
         assert torch.equal(m.generate(img.cuda(), 24, beam=k), best)          # deterministic
+        # two row ranges on two streams (the default from 256 beam rows on): ranges are whole images, slots range-local -> the same bits
+        import os
+        os.environ["TXO_LANES"] = "2"
+        try:
+            toks2, scores2 = m.generate(img.cuda(), 24, beam=k, return_beams=True)
+            assert m._engine.query(2) == 2
+        finally:
+            os.environ.pop("TXO_LANES")
+        assert torch.equal(toks2, toks) and torch.equal(scores2, scores)
     with pytest.raises(ValueError):
         m.generate(img.cuda(), 24, beam=9)
     with pytest.raises(ValueError):
         m.generate(torch.rand(5, 3, 64, 96, device="cuda"), 24, beam=3)       # 15 rows > max_batch 12
+
+
+def test_beam_search_two_row_ranges_at_300_rows_bit_identical_to_one():
+    """From 256 beam rows on, beam search decodes two row ranges (whole images each) on two streams, in bf16 with the latent cross
+    attention whose tiles take up to 16 heads = two beams of an image: same tokens and scores as ONE range."""
+    import os
+    d = Dims(canvas=224, max_len=16)
+    _, _, m = build(d, seed=9, dtype="bf16", max_batch=300)
+    img = torch.from_numpy(synth.synth_images(60, 3, 32, 64, seed=17)).cuda()
+    m.eos_token = None
+    t2, s2 = m.generate(img, 12, beam=5, return_beams=True)
+    assert m._engine.query(2) == 2 and m._engine.query(3) == 1
+    os.environ["TXO_LANES"] = "1"
+    try:
+        t1, s1 = m.generate(img, 12, beam=5, return_beams=True)
+        assert m._engine.query(2) == 1
+    finally:
+        os.environ.pop("TXO_LANES")
+    assert torch.equal(t1, t2) and torch.equal(s1, s2)
 
 
 def test_multipass_attention_panels():

@@ -858,9 +858,10 @@ struct Engine : EngineBase {
         DecAttnArgs<T> a{};
         a.y = dy + r0 * D; a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb; a.x_out = o.x_out;
         a.gamma = dec_g; a.beta = dec_b; a.D = D; a.W = o.W;
-        a.K = o.K + r0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + r0 * cfg.dec_heads * o.lmax * DH;
+        const size_t kr0 = o.cross ? r0 / o.kv_div : r0;      // cross panels are per IMAGE (kv_div beams share one)
+        a.K = o.K + kr0 * cfg.dec_heads * o.lmax * DH; a.V = o.V + kr0 * cfg.dec_heads * o.lmax * DH;
         a.out = dao + r0 * Id; a.heads = cfg.dec_heads; a.lmax = o.lmax; a.len = o.len; a.t_ptr = &st[li].t; a.t_host = step_host_t;
-        a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path; a.path_stride = Tmax;
+        a.qin = dq + r0 * Id; a.kv_div = o.kv_div; a.path = o.path ? o.path + r0 * Tmax : nullptr; a.path_stride = Tmax;   // slots are range-local
         a.kmask = kmask + r0 * Tmax; a.kmask_stride = Tmax;
         a.stamps = (ln.nb * cfg.dec_heads <= STAMP_BLOCKS) ? next_stamp(o.cross ? "attn cross" : "attn self") : nullptr;
         const dim3 grid(ln.nb * cfg.dec_heads), blk(256);
@@ -1068,8 +1069,8 @@ struct Engine : EngineBase {
                     done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp,
                     sample_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)r0};
         if (bm) {
-            BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok, bscore, bfin, bm->path_cur, bm->path_nxt, Tmax, bparent, btok, Bmax,
-                        st + li, done_flag + (size_t)li * Tmax, eos};
+            BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok + r0, bscore + r0, bfin + r0, bm->path_cur + r0 * Tmax, bm->path_nxt + r0 * Tmax, Tmax,
+                        bparent + r0, btok + r0, Bmax, st + li, done_flag + (size_t)li * Tmax, eos, (int)r0};
             hipLaunchKernelGGL(beam_select_kernel, dim3(nb / bm->k), dim3(256), 0, s, ba);
         } else if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(nb), dim3(64), (size_t)V * sizeof(float), s, sa);
         else hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
@@ -1553,41 +1554,77 @@ struct Engine : EngineBase {
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(rows)));
         if (!use_latent) ensure_ckv(s);                               // cross K/V of the B images
         sB = rows; sImg = B;                                          // decode rows are (image, beam) slots
+        last_persist = false;
         set_lanes(1, s);
+        // Two row ranges on two streams from 256 rows on, as generate() does beyond 128 images: one range's latency-bound projection
+        // launches run beside the other's HBM-bound attention launches.  A range is a whole number of IMAGES (beam_select_kernel ranks
+        // an image's k beams together; self-attention slots are range-local); every range has its own step state and done flags.
+        int want = (rows >= 256 && B >= 2 && !prof && !prof_cross && !g_dbg) ? 2 : 1;
+        if (const char* e = getenv("TXO_LANES")) want = std::max(1, std::min(std::min(atoi(e), 2), B));
+        if (want == 2) {
+            n_lanes = 2;
+            lanes[0].b0 = 0; lanes[0].nb = (B / 2) * beams; lanes[0].stream = s;
+            lanes[1].b0 = lanes[0].nb; lanes[1].nb = rows - lanes[0].nb; lanes[1].stream = lanes[1].own;
+        }
+        last_ranges = n_lanes;
         const int n = std::max(rows, Tmax);
         hipLaunchKernelGGL(beam_reset_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st, cur_tok, bscore, bfin, done_flag, rows,
                            beams, Tmax, cfg.bos);
+        for (int i = 1; i < n_lanes; ++i)                             // the other ranges' step state and flags (no rows: they were reset above)
+            hipLaunchKernelGGL(beam_reset_kernel, dim3((Tmax + 255) / 256), dim3(256), 0, s, st + i, cur_tok, bscore, bfin,
+                               done_flag + (size_t)i * Tmax, 0, beams, Tmax, cfg.bos);
+        if (n_lanes > 1) {
+            HIP_TRY(hipEventRecord(ev_fork, s));
+            for (int i = 1; i < n_lanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
+        }
         // same non-draining eos look as generate(): once every beam is finished further steps only repeat eos at no cost
-        // (beam_select_kernel), so the few steps enqueued ahead of the look change neither scores nor slots
+        // (beam_select_kernel), so the few steps enqueued ahead of the look change neither scores nor slots.  A range's flag stays
+        // set once set, so the batch is done at the first position at which every range's flag is set.
         int* flags = flags_host;
         int steps = max_len, cur = 0;
         const int CHUNK = 32, AHEAD = 4;
         int pend_lo = -1, pend_hi = -1;
-        bool stop = false;
+        bool stop = false, look_err = false;
+        auto look = [&]() {
+            for (int i = 0; i < n_lanes; ++i) if (hipEventSynchronize(ev_flags[i]) != hipSuccess) { look_err = true; return; }
+            for (int k2 = pend_lo; k2 <= pend_hi && !stop; ++k2) {
+                bool all = true;
+                for (int i = 0; i < n_lanes; ++i) all = all && flags[(size_t)i * Tmax + k2];
+                if (all) { steps = k2 + 1; stop = true; }
+            }
+            pend_lo = -1;
+        };
         for (int t = 0; t < max_len && !stop; ++t) {
             BeamCtx bm{beams, bpath[cur], bpath[cur ^ 1]};
-            if (int r2 = enqueue_step(s, 0, nullptr, 0, nullptr, eos, &bm, t)) return r2;
+            for (int i = 0; i < n_lanes; ++i)
+                if (int r2 = enqueue_step(lanes[i].stream, i, nullptr, 0, nullptr, eos, &bm, t)) return r2;
             cur ^= 1;
             if (eos < 0) continue;
             const bool last = t + 1 == max_len;
             if ((t + 1) % CHUNK == 0 || last) {
                 if (pend_lo >= 0) {                                   // (only when CHUNK <= AHEAD; kept for safety)
-                    HIP_TRY(hipEventSynchronize(ev_flags[0]));
-                    for (int i = pend_lo; i <= pend_hi && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
-                    pend_lo = -1;
+                    look();
+                    if (look_err) return fail(TXO_E_HIP, "beam search: waiting for the done flags failed");
                     if (stop) break;
                 }
                 const int lo = (t / CHUNK) * CHUNK;
-                HIP_TRY(hipMemcpyAsync(flags + lo, done_flag + lo, sizeof(int) * (t + 1 - lo), hipMemcpyDeviceToHost, s));
-                HIP_TRY(hipEventRecord(ev_flags[0], s));
+                for (int i = 0; i < n_lanes; ++i) {
+                    HIP_TRY(hipMemcpyAsync(flags + (size_t)i * Tmax + lo, done_flag + (size_t)i * Tmax + lo, sizeof(int) * (t + 1 - lo),
+                                           hipMemcpyDeviceToHost, lanes[i].stream));
+                    HIP_TRY(hipEventRecord(ev_flags[i], lanes[i].stream));
+                }
                 pend_lo = lo; pend_hi = t;
             }
             if (pend_lo >= 0 && (t == pend_hi + AHEAD || last)) {
-                HIP_TRY(hipEventSynchronize(ev_flags[0]));
-                for (int i = pend_lo; i <= pend_hi && !stop; ++i) if (flags[i]) { steps = i + 1; stop = true; }
-                pend_lo = -1;
+                look();
+                if (look_err) return fail(TXO_E_HIP, "beam search: waiting for the done flags failed");
             }
         }
+        for (int i = 1; i < n_lanes; ++i) {                           // join the ranges back into the caller's stream
+            HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
+            HIP_TRY(hipStreamWaitEvent(s, ev_join[i], 0));
+        }
+        set_lanes(1, s);
         // backtrack every beam into tok_buf rows, then hand out the best beam (slot 0: selection order is by score)
         hipLaunchKernelGGL(beam_backtrack_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, bparent, btok, Bmax, steps, rows,
                            tok_buf, Tmax);

@@ -299,6 +299,8 @@ struct BeamArgs {
     const short* path_cur; short* path_nxt; int path_stride;   // [rows][tmax] slot of every history position
     short* parent_hist; int* tok_hist; int hist_stride;        // [tmax][rows] back-pointers for the final backtrack
     StepState* st; int* done_flag; int eos;
+    int row0;                             // this row range's first row in the batch: every pointer above is the RANGE's (slots in `path` are range-local,
+                                          // like the range's K/V base), only the back-pointers name rows of the whole batch (beam_backtrack_kernel)
 };
 
 __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
                 const int row = img * k + r;
                 a.score[row] = sv[r]; a.fin[row] = nf; a.cur_tok[row] = v;
                 a.tok_hist[(size_t)t * a.hist_stride + row] = v;
-                a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(img * k + j);
+                a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(a.row0 + img * k + j);
             }
             const short* src = a.path_cur + (size_t)(img * k + j) * a.path_stride;
             short* dst = a.path_nxt + (size_t)(img * k + r) * a.path_stride;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
             const int row = img * k + r;
             a.score[row] = selv[r]; a.fin[row] = nf; a.cur_tok[row] = v;
             a.tok_hist[(size_t)t * a.hist_stride + row] = v;
-            a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(img * k + j);
+            a.parent_hist[(size_t)t * a.hist_stride + row] = (short)(a.row0 + img * k + j);
         }
         // history slots of the new beam: the parent's, plus the parent's own slot for position t
         const short* src = a.path_cur + (size_t)(img * k + j) * a.path_stride;
