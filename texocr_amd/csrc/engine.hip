@@ -1560,11 +1560,15 @@ struct Engine : EngineBase {
         // launches run beside the other's HBM-bound attention launches.  A range is a whole number of IMAGES (beam_select_kernel ranks
         // an image's k beams together; self-attention slots are range-local); every range has its own step state and done flags.
         int want = (rows >= 256 && B >= 2 && !prof && !prof_cross && !g_dbg) ? 2 : 1;
-        if (const char* e = getenv("TXO_LANES")) want = std::max(1, std::min(std::min(atoi(e), 2), B));
-        if (want == 2) {
-            n_lanes = 2;
-            lanes[0].b0 = 0; lanes[0].nb = (B / 2) * beams; lanes[0].stream = s;
-            lanes[1].b0 = lanes[0].nb; lanes[1].nb = rows - lanes[0].nb; lanes[1].stream = lanes[1].own;
+        if (const char* e = getenv("TXO_LANES")) want = std::max(1, std::min(std::min(atoi(e), max_lanes), B));
+        if (want > 1) {
+            n_lanes = want;
+            int img0 = 0;
+            for (int i = 0; i < want; ++i) {
+                const int ni = B / want + (i < B % want ? 1 : 0);
+                lanes[i].b0 = img0 * beams; lanes[i].nb = ni * beams; lanes[i].stream = i == 0 ? s : lanes[i].own;
+                img0 += ni;
+            }
         }
         last_ranges = n_lanes;
         const int n = std::max(rows, Tmax);
