@@ -18,6 +18,10 @@ prof b256 --batch 256
 TXO_LANES=1 prof b256_one_range --batch 256
 TXO_LANES=1 TXO_LATENT=0 TXO_PERSIST=0 prof b256_one_range_kvform --batch 256
 prof cfg4 --batch 256 --model cfg4 --steps 2
+TXO_LANES=1 prof cfg4_one_range --batch 256 --model cfg4 --steps 2
+# beam search at the BASELINE configs[4] shape (128 images x 5 beams, 224x672): two row ranges (default) and one
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r04_cfg5 -- python3 probes/cfg5_prof.py > $O/prof_r04_cfg5.log 2>&1
+f=$(find $O/prof_r04_cfg5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/r04_cfg5_beam_final_kernel_stats.csv
 bash probes/collect_pmc.sh bf16 64 256
 TXO_PMC_TAG=latent bash probes/collect_pmc.sh bf16 256
 TXO_PMC_TAG=kvform TXO_LATENT=0 bash probes/collect_pmc.sh bf16 256
