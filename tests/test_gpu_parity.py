@@ -857,7 +857,7 @@ def test_wide_decoder_large_batch_ffn_path():
 
 
 def test_folded_out_projection_on_32_row_blocks_bit_identical_to_16_row_blocks():
-    """From 512 decode rows on (a beam search's rows), the latent form's folded output projection (K = heads * D = 2048) runs on
+    """Beyond 256 decode rows per range (a beam search's rows), the latent form's folded output projection (K = heads * D = 2048) runs on
     32-row blocks that share their weight fragments (dec_gemm_wide_kernel<EPI_GLU_RES, 16, 32, 2>): same K split, same reduction
     order, same epilogue as the 16-row tile -> the same bits.  520 rows on ONE row range against the engine with that routing off."""
     import os

@@ -147,6 +147,7 @@ struct Engine : EngineBase {
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
+    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 257;   // narrow decoder: rows from which the folded out-projection runs on 32-row blocks
     bool kw24_off = getenv("TXO_KW24_OFF") != nullptr;    // experiment switch: FFN-out at K = 3072 on the run-time-K tile (three request groups) instead of the fixed one
     // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
     // measured +22 % for a plain 256x256 store epilogue at K = 768 (1.85 GB of output per launch), but the encoder's own epilogues
@@ -829,8 +830,9 @@ struct Engine : EngineBase {
             constexpr int KCH = Elem<T>::KCHUNK;
             const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
             // narrow decoder: only the folded latent output projection (K = heads * D = 2048) of a beam search's many rows -- 640 rows are
-            // 1280 16-row blocks of 128 KB each (19.6 us); at 256 rows the 32-row blocks are too few to fill the chip (measured slower)
-            if (D < 512 && !(kw == 16 && a.rows >= 512 && EPI == EPI_GLU_RES)) return false;
+            // 1280 16-row blocks of 128 KB each (19.6 us on one range; on two ranges of 320 rows the 32-row blocks give 1066 -> 1130 img/s).
+            // Up to 256 rows per range they change nothing (batch 256: 76.1 vs 76.4 ms on two ranges, 82.0 vs 81.5 on one)
+            if (D < 512 && !(kw == 16 && a.rows >= wide_min_rows && EPI == EPI_GLU_RES)) return false;
             a.stamps = nullptr;
 #define TXO_DGW(KW_, BN_, RT_)                                                                                              \
             do {                                                                                                            \
@@ -839,7 +841,7 @@ struct Engine : EngineBase {
                 return true;                                                                                                \
             } while (0)
             if (kw == 6) TXO_DGW(6, 32, 4);                  // K = 768: the gated out-projections, FFN-in behind its LayerNorm launch
-            if constexpr (EPI == EPI_GLU_RES) { if (kw == 16) TXO_DGW(16, 32, 2); }
+            if constexpr (EPI == EPI_GLU_RES) { if (kw == 16) TXO_DGW(16, 32, 2); }   // (16 columns and / or 64 rows per block: 1080-1084 against 1134 img/s at the beam shape)
 #undef TXO_DGW
             return false;
         }
