@@ -960,6 +960,27 @@ def test_persistent_decode_samples_like_the_launch_path(dtype, B):
         assert torch.equal(a, b) and a.shape[1] <= 40
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_sampled_decode_draws_do_not_depend_on_the_row_ranges(dtype):
+    """A draw is keyed by (seed; row of the BATCH, position): two row ranges on two streams (the default for bf16 beyond 223 images,
+    sampled like greedy) sample the same tokens from the same logits as one range."""
+    import os
+    d = Dims(canvas=224)
+    d, sd, m = build(d, seed=3, dtype=dtype, max_batch=48)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    img = torch.rand((48, 3, 64, 224), generator=g, device="cuda")
+    outs = []
+    for lanes in ("1", "2"):
+        os.environ["TXO_LANES"] = lanes
+        try:
+            outs.append(m.generate(img, 24, temp=0.3, decode="sample", seed=11, return_logits=True))
+            assert m._engine.query(0) == 0 and m._engine.query(2) == int(lanes)
+        finally:
+            os.environ.pop("TXO_LANES")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert not torch.equal(outs[0][0], m.generate(img, 24))              # and they are draws, not arg-maxes
+
+
 def test_persistent_decode_gives_up_cleanly_and_launches_take_over():
     """The persistent launch waits on other workgroups with bounded spins; when a hand-off times out (or a team turns out to
     span two XCDs) every workgroup leaves, the engine reports it and redoes the decode with launches.  A test hook makes

@@ -907,7 +907,7 @@ struct Engine : EngineBase {
     // 64); wide decoders (768: the in-tile projections' weights are 3.4 MB per row) and the fp32 parity mode keep the K/V form.
     // the latent form's two per-head projections fold into their neighbouring GEMMs (load_attn) where the folded weights stay small
     bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D && getenv("TXO_LAT_NOFOLD") == nullptr; }
-    bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY && !sample_mode; }
+    bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY; }
     // heads per latent tile: the smallest group that leaves at most one tile per CU for `rows` rows (fewer tiles = fewer
     // re-reads of an image's encoder rows; more tiles = more CUs pulling).  A head's bits do not depend on it.
     int latent_group(int rows, int slots) const {
@@ -1068,8 +1068,7 @@ struct Engine : EngineBase {
         dbg(s, "logits");
         StepArgs sa{llog, V, nb, cur_tok + r0, tokens_out ? tokens_out + r0 * out_stride : nullptr, out_stride,
                     logits_out ? logits_out + r0 * (size_t)out_stride * V : nullptr, st + li, eos_seen + r0,
-                    done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp,
-                    sample_seed + 0x9E3779B97F4A7C15ull * (unsigned long long)r0};
+                    done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp, sample_seed, (int)r0};
         if (bm) {
             BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok + r0, bscore + r0, bfin + r0, bm->path_cur + r0 * Tmax, bm->path_nxt + r0 * Tmax, Tmax,
                         bparent + r0, btok + r0, Bmax, st + li, done_flag + (size_t)li * Tmax, eos, (int)r0};
@@ -1248,10 +1247,10 @@ struct Engine : EngineBase {
         if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
         if (persist_cooldown > 0) return false;                // it gave up twice in a row (not all 256 workgroups co-resident?): not tried for a while
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
-        // bf16 greedy beyond 128 images: launches on TWO row ranges (two streams: one range's latency-bound projections beside the
-        // other's HBM-bound attention) are 4-7 % ahead of the persistent launch (144: 67.2 vs 69.6 ms, 160: 66.9 vs 71.8, 192: 75.1 vs 78.9, 256: 94.2
-        // vs 97.7; at 128 the persistent launch leads 53.7 vs 59.3); fp32 and sampled decode: persistent up to 256
-        if (sizeof(T) == 2 && !sample_mode && B > PERSIST_MAX_BF16_GREEDY) return false;
+        // bf16 beyond 128 images: launches with the cross attention in latent form (one row range, two from 224 rows on) are ahead of the
+        // persistent launch -- greedy 160: 66.6 vs 72.7 ms, 192: 70.6 vs 79.7, 256: 77.9 vs 99.0; sampled 160: 68.9 vs 73.4, 192: 73.0 vs 80.6, 256: 84.5
+        // (one range) vs 99.7; at 128 the persistent launch leads (greedy 54.2 vs 56.7, sampled 55.2 vs 58.4).  fp32: persistent up to 256
+        if (sizeof(T) == 2 && B > PERSIST_MAX_BF16_GREEDY) return false;
         return B <= 256;                                       // more rows per team than two 16-row tiles: not measured
     }
     template <int D_, int H_>
@@ -1428,10 +1427,10 @@ struct Engine : EngineBase {
         const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
         const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
         // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
-        // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765); greedy only -- the sampler's
-        // counter RNG is keyed per range
-        // (also the narrow decoder's bf16 greedy decode beyond the persistent launch's range, see persist_usable)
-        int want = (sizeof(T) == 2 && !sample_mode && !prof && !prof_cross &&       // (profiling times whole-batch launches)
+        // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765).  Greedy and sampled alike: a draw is keyed
+        // by (seed; row of the batch, position), not by the range (step.h: StepArgs::row0)
+        // (also the narrow decoder's bf16 decode beyond the persistent launch's range, see persist_usable)
+        int want = (sizeof(T) == 2 && !prof && !prof_cross &&       // (profiling times whole-batch launches)
                     ((D >= 512 && B >= 256) || (D < 512 && B > PERSIST_MAX_BF16_GREEDY))) ? 2 : 1;
         // in latent form the second range pays from ~224 rows on (160: 66.6 ms with one range vs 71.7 with two, 192: 70.6 vs 72.2, 256: 82.0 vs 77.9;
         // K/V form: two ranges from 129 on, 160: 70.9 vs 66.3)
@@ -1525,7 +1524,7 @@ struct Engine : EngineBase {
         for (int i = n_pos; i < max_len; ++i) {
             if (int r = prefill(tokens_out + (i - Tmax), max_len, Tmax, nullptr, dlogits, s)) return r;
             hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, i);
-            StepArgs sa{dlogits, V, B, cur_tok, tokens_out, max_len, logits_out, st, eos_seen, flag - i, eos, sample_topk, 1.0f / sample_temp, sample_seed};
+            StepArgs sa{dlogits, V, B, cur_tok, tokens_out, max_len, logits_out, st, eos_seen, flag - i, eos, sample_topk, 1.0f / sample_temp, sample_seed, 0};
             if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(64), (size_t)V * sizeof(float), s, sa);
             else hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
             *steps = i + 1;

@@ -30,6 +30,7 @@ struct StepArgs {
     StepState* st; int* eos_seen; int* done_flag; int eos;   // eos < 0: no eos check
     // sampling (reference decoder.py:104-108): keep the topk largest logits, softmax(logits / temp), draw one
     int topk; float inv_temp; unsigned long long seed;
+    int row0;                   // first row of this row range in the batch: a draw is keyed by (seed; row of the BATCH, t), whatever the ranges
 };
 
 // append the chosen token, update the GLOBAL eos bookkeeping, advance the device-side position (lane 0 of a row)
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     const int t = a.st->t;
     const float* lg = a.logits + (size_t)row * V;
     float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
-    const int pick = sample_row([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
+    const int pick = sample_row([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)(a.row0 + row), (unsigned)t);
     if (lane == 0) commit_token(a, row, t, pick);
 }
 
