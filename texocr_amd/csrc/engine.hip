@@ -737,8 +737,8 @@ struct Engine : EngineBase {
         sB = B; sN = N; sImg = B; session = true;
         ckv_valid = false;
         kmask_on = false;
-        // a session opened through the C entry point steps with launches: latent form only when forced
-        use_latent = latent_ok && lat_mode == 1;
+        // a session opened through the C entry point steps with launches: it takes the form generate()'s launches take at this batch size
+        use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
         if (!use_latent && project_kv) ensure_ckv(s);
         set_lanes(1, s);
         reset_lanes(s, eos);
