@@ -724,6 +724,18 @@ def test_beam_search_two_row_ranges_at_300_rows_bit_identical_to_one():
     finally:
         os.environ.pop("TXO_LANES")
     assert torch.equal(t1, t2) and torch.equal(s1, s2)
+    # with an eos (the most frequent token of the best beams): finished beams repeat eos at no cost, the loop stops only when EVERY
+    # range's beams are finished -- same length, same beams, same scores on one range and on two
+    vals, counts = np.unique(t2[:, 0].cpu().numpy(), return_counts=True)
+    m.eos_token = int(vals[counts.argmax()])
+    e2 = m.generate(img, 12, beam=5, return_beams=True)
+    os.environ["TXO_LANES"] = "1"
+    try:
+        e1 = m.generate(img, 12, beam=5, return_beams=True)
+    finally:
+        os.environ.pop("TXO_LANES")
+    assert e1[0].shape == e2[0].shape and torch.equal(e1[0], e2[0]) and torch.equal(e1[1], e2[1])
+    assert not torch.equal(e2[0], t2[:, :, :e2[0].shape[2]]) or e2[0].shape[2] < 12      # the eos changed something
 
 
 def test_multipass_attention_panels():
