@@ -667,18 +667,21 @@ def test_custom_ops_and_module_state_dict():
     assert bool((m2.generate(img, 4) == 5).all())
 
 
+@pytest.mark.parametrize("latent", [None, 1], ids=["kv_form", "latent_form"])
 @pytest.mark.parametrize("vocab", [1000, 1100], ids=["rows_in_registers", "general_path"])
-def test_beam_search_extension(vocab):
+def test_beam_search_extension(vocab, latent):
     """BASELINE config 5 asks for beam search; the reference has none, so parity is anchored at
     beams=1 == greedy, plus agreement with the oracle's independent CPU restatement of the same definition.
     Both forms of beam_select_kernel (csrc/step.h): an image's k rows in registers up to 1024 entries, the general path beyond."""
     cpu_ref = _oracle()
     d = Dims(canvas=224, vocab=vocab)
-    d, sd, m = build(d, seed=0, max_batch=12)
+    # latent_form: the cross attention against the raw encoder rows, an image's k beams as ONE row of k * heads heads (16 per tile)
+    d, sd, m = build(d, seed=0, max_batch=12, latent=latent)
     img = torch.from_numpy(synth.synth_images(3, 3, 64, 96, seed=41))
     m.eos_token = None
     greedy = m.generate(img.cuda(), 24)
     assert torch.equal(m.generate(img.cuda(), 24, beam=1), greedy)
+    assert m._engine.query(3) == (1 if latent else 0)
     sdt = cpu_ref.to_torch_sd(sd)
     enc = cpu_ref.encode(sdt, img)
     for k, eos in ((4, None), (3, int(greedy[0, 5]))):
