@@ -130,7 +130,8 @@ int txo_generate_beam(txo_engine* e, const float* img_dev, int32_t B, int32_t C,
 /* Token selection for the following decode steps / generate calls.  mode 0 (default): greedy argmax.  mode 1:
  * the reference's sampler (decoder.py:104-108 + utils.topk, utils.py:85-91): keep the `topk` largest logits
  * (the reference uses int((1 - 0.9) * vocab) = 99 for vocab 1000), softmax(logits / temp), one multinomial draw,
- * from a counter-based RNG keyed by `seed` (reproducible; a different stream than torch.multinomial). */
+ * from a counter-based RNG keyed by (`seed`; row of the batch, position): reproducible, independent of the decode path and of
+ * how the engine splits the batch into row ranges; a different stream than torch.multinomial. */
 int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed);
 
 /* Timing hooks for bench.py: average duration (ms) of the decode-step cross-attention launches and of
