@@ -809,39 +809,52 @@ def test_large_ragged_batch_rows_independent():
 def test_bf16_dma_gemm_bit_identical_to_register_staged(monkeypatch):
     """The 256x256 LDS-DMA GEMM (gemm_pp.h) and the 128x128 register-staged GEMM (gemm_big.h) accumulate every output element in
     the same order, so the bf16 engine must give bit-identical encoder features and tokens with either (TXO_GEMM_OLD=1 forces
-    the latter).  Ragged row count (B * 589 is not a multiple of 256) and every epilogue (heads scatter, GLU + residual, GeGLU,
-    bias + residual, cross K/V store) are on the path; repeated to screen for timing-dependent races."""
+    the latter) -- and with either EPILOGUE form of the former: TXO_PP_TR=1 runs every epilogue straight from the transposed
+    accumulators (weight rows permuted on their way into LDS), =0 stages every one through LDS, unset picks per epilogue (r05).
+    Ragged row count (B * 589 is not a multiple of 256: the tile-seam's relaxed wait must fall back on the last row panel) and
+    every epilogue (heads scatter, GLU + residual, GeGLU, bias + residual, cross K/V store) are on the path; repeated to screen
+    for timing-dependent races (the seam's early request / counted wait)."""
+    def build_with(env, *a, **kw):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            return build(*a, **kw)[2]
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+    forms = ({}, {"TXO_PP_TR": "1"}, {"TXO_PP_TR": "0"})
     d = Dims(canvas=672)
     img = torch.from_numpy(synth.synth_images(12, 3, 224, 672, seed=91)).cuda()
-    monkeypatch.setenv("TXO_GEMM_OLD", "1")
-    _, _, m_old = build(d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
-    monkeypatch.delenv("TXO_GEMM_OLD")
-    _, _, m_new = build(d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
-    m_old.eos_token = None; m_new.eos_token = None
+    m_old = build_with({"TXO_GEMM_OLD": "1"}, d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
+    m_old.eos_token = None
     enc_old = m_old.encoder(img)
-    for _ in range(25):
-        assert torch.equal(m_new.encoder(img), enc_old)
     t_old, l_old = m_old.generate(img, 24, return_logits=True)
-    t_new, l_new = m_new.generate(img, 24, return_logits=True)
-    assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old)
-    # ViT-Base widths (K = 768 / 3072: 12 and 48 K tiles)
+    for env in forms:
+        m_new = build_with(env, d, seed=4, dtype="bf16", max_batch=12, max_tokens=589)
+        m_new.eos_token = None
+        for _ in range(25):
+            assert torch.equal(m_new.encoder(img), enc_old), env
+        t_new, l_new = m_new.generate(img, 24, return_logits=True)
+        assert torch.equal(t_new, t_old) and torch.equal(l_new, l_old), env
+    # ViT-Base widths (K = 768 / 3072: 12 and 48 K tiles); 20 images: 47 row panels, several tiles per workgroup (the seam between tiles)
     d2 = Dims(canvas=672, embed_dim=768, enc_heads=12, enc_layers=2, dec_heads=12, dec_layers=1)
-    monkeypatch.setenv("TXO_GEMM_OLD", "1")
-    _, _, b_old = build(d2, seed=6, dtype="bf16", max_batch=12, max_tokens=589)
-    monkeypatch.delenv("TXO_GEMM_OLD")
-    _, _, b_new = build(d2, seed=6, dtype="bf16", max_batch=12, max_tokens=589)
-    ref = b_old.encoder(img)
-    for _ in range(15):
-        assert torch.equal(b_new.encoder(img), ref)
+    img20 = torch.from_numpy(synth.synth_images(20, 3, 224, 672, seed=93)).cuda()
+    b_old = build_with({"TXO_GEMM_OLD": "1"}, d2, seed=6, dtype="bf16", max_batch=20, max_tokens=589)
+    ref, ref20 = b_old.encoder(img), b_old.encoder(img20)
+    for env in forms:
+        b_new = build_with(env, d2, seed=6, dtype="bf16", max_batch=20, max_tokens=589)
+        for _ in range(10):
+            assert torch.equal(b_new.encoder(img), ref), env
+            assert torch.equal(b_new.encoder(img20), ref20), env
     # default-factory model: the hybrid embedder's 1x1 projection (position rows added in the epilogue, K = 1024)
     from texocr_amd.config import reference_config
     dh = Dims.from_config(reference_config())
     imgh = torch.from_numpy(synth.synth_images(4, 1, 160, 1008, seed=92)).cuda()
-    monkeypatch.setenv("TXO_GEMM_OLD", "1")
-    _, _, h_old = build(dh, seed=8, dtype="bf16", max_batch=4)
-    monkeypatch.delenv("TXO_GEMM_OLD")
-    _, _, h_new = build(dh, seed=8, dtype="bf16", max_batch=4)
-    assert torch.equal(h_new.encoder(imgh), h_old.encoder(imgh))
+    h_old = build_with({"TXO_GEMM_OLD": "1"}, dh, seed=8, dtype="bf16", max_batch=4)
+    ref_h = h_old.encoder(imgh)
+    for env in forms:
+        h_new = build_with(env, dh, seed=8, dtype="bf16", max_batch=4)
+        assert torch.equal(h_new.encoder(imgh), ref_h), env
 
 
 def test_wide_decoder_large_batch_ffn_path():

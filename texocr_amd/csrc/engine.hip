@@ -163,6 +163,7 @@ struct Engine : EngineBase {
     int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
+    int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
@@ -600,7 +601,7 @@ struct Engine : EngineBase {
     template <class Epi>
     void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi) {
         if constexpr (sizeof(T) == 2) {
-            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi); return; }
+            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr); return; }
         }
         launch_gemm_big<T>(s, LoadPlain<T>{A, K}, W, M, N, K, epi);
     }

@@ -72,6 +72,8 @@ __device__ inline void load8(const float* p, float (&v)[8]) {
 template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
     T* out; int ldo; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
+    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;   // 16-byte store instructions per fin() (gemm_pp.h counts a tile's stores)
+    static constexpr int NCB = 8;                       // entries of cb[] that cols() fills
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         if (bias) { float b[8]; load8(bias + n, b);
 #pragma unroll
@@ -96,6 +98,8 @@ template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
 template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
     T* base; size_t which_stride; int inner, heads, ntok; int nt = 0;
     static constexpr bool PAIRED = false;
+    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;
+    static constexpr int NCB = 0;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
         const int b = m / ntok, t = m - b * ntok;
@@ -135,6 +139,8 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
     float* y; ResidLN res; const float* bias;     // bias is in the interleaved order
     int nt = 0;
     static constexpr bool PAIRED = true;
+    static constexpr int ST = 2;
+    static constexpr int NCB = 32;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8], r[10], cg[16];
         load8(bias + nv, bv); load8(bias + ng, bg); res.load(m, j, r); res.cols(j, cg);
@@ -158,6 +164,8 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
 template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
     T* h; const float* bias; int F; int nt = 0;
     static constexpr bool PAIRED = true;
+    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;
+    static constexpr int NCB = 16;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8];
         load8(bias + nv, bv); load8(bias + ng, bg);
@@ -179,6 +187,8 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
 struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
     float* y; ResidLN res; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
+    static constexpr int ST = 2;
+    static constexpr int NCB = 24;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         float b[8], r[10], cg[16];
         load8(bias + n, b); res.load(m, n, r); res.cols(n, cg);
@@ -188,12 +198,12 @@ struct EpiBiasRes {                               // y[m][n..] = acc + bias + re
     }
     static constexpr bool HAS_ROW = true;
     __device__ inline void cols(int n, float (&cb)[32]) const {
-        load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); res.cols(n, reinterpret_cast<float (&)[16]>(cb[16]));
+        load8(bias + n, reinterpret_cast<float (&)[8]>(cb)); res.cols(n, reinterpret_cast<float (&)[16]>(cb[8]));
     }
     __device__ inline void rowop(int m, int n, float (&r)[10]) const { res.load(m, n, r); }
     __device__ inline void fin(int m, int n, float (&v)[8], const float (&cb)[32], const float (&r)[10], bool valid) const {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += cb[e] + res.value(r, reinterpret_cast<const float (&)[16]>(cb[16]), e);
+        for (int e = 0; e < 8; ++e) v[e] += cb[e] + res.value(r, reinterpret_cast<const float (&)[16]>(cb[8]), e);
         if (valid) store8<float>(y + (size_t)m * res.D + n, v, nt);
     }
 };
