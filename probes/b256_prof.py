@@ -1,0 +1,14 @@
+"""batch-256 bf16 greedy decode for rocprofv3 (probes/prof_py.sh): 3 generates of 256 steps on the default path (env decides the forms)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from texocr_amd.config import Dims
+from texocr_amd import synth
+from texocr_amd.model import model_from_dims
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+d = Dims(canvas=672)
+m = model_from_dims(d, dtype="bf16", max_batch=B, max_tokens=589)
+m.load_state_dict(synth.synth_state_dict(d, 0)); m.eos_token = None
+img = torch.rand((B, 3, 224, 672), device="cuda")
+for _ in range(3): m.generate(img, 256)
+torch.cuda.synchronize()

@@ -12,7 +12,8 @@
 //   EPI_GEGLU : h = (v+b)*gelu_erf(g+b)                    (attention.py:15-17)
 //   EPI_BIAS_RES: y = acc + b + residual                   (attention.py:66, :35-38)
 //   EPI_LOGITS: logits = acc + b                           (decoder.py:60, last position only)
-//   EPI_STORE_T: out = acc in the storage type -> h_out [rows][F]   (latent cross attention: the q projection, lat_attn.h)
+//   EPI_STORE_T: out = acc in the storage type -> h_out [rows][F]   (latent attention: the q / q' projection, lat_attn.h; with z_cache the
+//                normalised input rows are appended to the self attention's latent history)
 //
 // These launches are latency chains, not throughput kernels (a few MFLOP each), so the structure minimises
 // dependent memory round trips: output tile = 16 rows x 32 columns per 256-thread block (many small blocks
@@ -110,6 +111,8 @@ template <typename T> struct DecGemmArgs {
     int inner, heads, tmax;
     const float* resid; float* y_out; int D;    // y_out [rows][D]
     T* h_out; int F;                // [rows][F]
+    T* z_cache;                     // EPI_STORE_T behind PRO_EMBED / PRO_LN2, or null: the normalised rows z (the block input) are also stored at
+                                    // position t of [rows][tmax][K] -- the self attention's history in latent form (lat_attn.h)
     float* logits;                  // [rows][N]
     unsigned long long* stamps;     // diagnostic (TXO_STAMPS): per block {entry, operands landed, exit} in 10 ns ticks; null normally
 };
@@ -267,7 +270,7 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
         e_res0 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + na); e_res1 = ldc_f32<COH>(a.resid + (size_t)emc * a.D + nb);
     }
     int t = 0;
-    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
+    if constexpr (PRO == PRO_EMBED || EPI == EPI_QKV || (EPI == EPI_STORE_T && PRO != PRO_NONE)) t = a.t_host >= 0 ? a.t_host : *a.t_ptr;
     if constexpr (PRO == PRO_NONE) { load_a_global(0); pf(); }
     // keep every fragment load ahead of the first MFMA: with K fixed this is one basic block and the machine
     // scheduler would otherwise interleave loads and MFMAs four at a time (serialising the memory latency)
@@ -304,16 +307,22 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
             }
         }
         ln16<NVMAX, sizeof(T) == 2>(v, nv, g, b, inv_d);
+        // z in the storage type: the A image of this tile -- and, for the latent self attention, row t of this row's history
+        // (exactly the rounded values the K/V form's k and v projections multiply: attention.py:114-127 with kv_input = x)
+        [[maybe_unused]] T* zrow = nullptr;
+        if constexpr (EPI == EPI_STORE_T) { if (a.z_cache && bx == 0 && valid && m0 + r < rows) zrow = a.z_cache + ((size_t)m * a.tmax + t) * K; }
 #pragma unroll
         for (int i = 0; i < NVMAX; ++i) if (i < nv) {
             unsigned char* dst = smem + a_off<T>(r, i * 64 + sub * 4, row_bytes, pmask);
             if constexpr (sizeof(T) == 4) {
                 *reinterpret_cast<float4*>(dst) = v[i];
+                if constexpr (EPI == EPI_STORE_T) { if (zrow) *reinterpret_cast<float4*>(zrow + i * 64 + sub * 4) = v[i]; }
             } else {
                 union { bf16 h[4]; uint2 u; } c;
                 c.h[0] = __float2bfloat16(v[i].x); c.h[1] = __float2bfloat16(v[i].y);
                 c.h[2] = __float2bfloat16(v[i].z); c.h[3] = __float2bfloat16(v[i].w);
                 *reinterpret_cast<uint2*>(dst) = c.u;
+                if constexpr (EPI == EPI_STORE_T) { if (zrow) *reinterpret_cast<uint2*>(zrow + i * 64 + sub * 4) = c.u; }
             }
         }
         __syncthreads();

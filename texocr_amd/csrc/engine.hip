@@ -126,6 +126,7 @@ struct Engine : EngineBase {
     T* enc_t = nullptr;               // bf16 copy of the encoder output (A operand of the cross K/V GEMM)
     T *ckv = nullptr, *skv = nullptr;  // cross [Ld][2][B*h][N][64], self [Ld][2][B*h][Tmax][64]
     float *dx = nullptr, *dy = nullptr, *dq = nullptr, *dlogits = nullptr; T *dao = nullptr, *dhid = nullptr, *dz = nullptr;
+    T* zc = nullptr;                  // self attention in latent form: history of normalised block inputs [Ld][B][Tmax][D] (lat_attn.h)
     T *dqt = nullptr, *dqp = nullptr, *dcl = nullptr;   // latent cross attention: q [B][inner], q' and c [B][heads*D] in the storage type
     int64_t* cur_tok = nullptr; int *eos_seen = nullptr, *done_flag = nullptr; StepState* st = nullptr;
     unsigned char* kmask = nullptr; bool kmask_on = false;   // padding mask over the decoded positions of a decode_step session (txo_decode_set_key_mask)
@@ -158,7 +159,18 @@ struct Engine : EngineBase {
     // cross attention in latent form (lat_attn.h): scores / values against the raw encoder rows instead of projected K/V panels.
     // latent_ok: the tile exists for this engine's width / storage type.  lat_mode (TXO_LATENT, read once): 1 = every decode runs with
     // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
-    bool latent_ok = false, use_latent = false, la_attr_set = false;
+    bool latent_ok = false, use_latent = false;
+    // lat_self: this session's SELF attention also runs in latent form (the history is z, not k / v: a quarter of the bytes at config.yml
+    // dims).  Only inside generate() / generate_beam() with launches in latent form: a session opened through txo_decode_begin may be
+    // prefilled or masked, which work on the K/V history.  OPT-IN (TXO_LATENT_SELF=1, read once per engine): measured on MI355X it
+    // ties the K/V history at batch 256 (76.5 vs 76.7 ms per generate: the core is 9.8 us against 14.8 for the K/V kernel, averaged over
+    // the 256 positions, but the folded output projection's K = heads*D costs 9.1 us against 4.8) and loses in beam search (121 vs 115 ms
+    // at 5 x 128); what it saves is history capacity (a quarter).  profiles/r05_latent_self.txt.
+    bool lat_self = false;
+    int lat_self_env = getenv("TXO_LATENT_SELF") ? atoi(getenv("TXO_LATENT_SELF")) : 0;
+    bool lat_self_ok() const {
+        return lat_self_env != 0 && !dec_self.empty() && dec_self[0].wqp != nullptr && Tmax <= 16 * (D <= 256 ? 8 : 4) * LA_PATH_TILES;
+    }
     int lat_mode = getenv("TXO_LATENT") ? atoi(getenv("TXO_LATENT")) : -1;
     int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
@@ -289,6 +301,40 @@ struct Engine : EngineBase {
         return upload_f32(b, b0->data);
     }
 
+    // inner == 2 D (config.yml dims: 8 heads of 64 at width 256): the latent form's two per-head projections fold into their neighbours at
+    // load time (products in double, rounded once to the storage type) and an attention sub-layer is THREE launches instead of five:
+    //   q'[h*D + d'] = sum_d z[d] * M[h*D + d'][d],   M = 0.125 Wk_h^T Wq_h            (in the LN-prologue GEMM, N = heads*D)
+    //   y[n]         = sum_{h,d} c[h*D + d] * Wo'[n][h*D + d],  Wo' = Wo[:, h] Wv_h     (in the gated output projection, K = heads*D)
+    // (attention.py:124-127,148,166,172-173: k and v are linear images of the SAME D-element row -- the raw encoder row in the cross
+    // attention, the normalised block input in the self attention, attention.py:114-116)
+    int fold_latent(const HostTensor* q, const HostTensor* k, const HostTensor* v, const HostTensor* wo, int inner, AttnW* w, int G) {
+        const int H = inner / DH, HD = H * D;
+        std::vector<float> M((size_t)HD * D), WoF((size_t)2 * D * HD);
+        std::vector<double> acc(std::max(D, HD));
+        for (int h = 0; h < H; ++h)
+            for (int d1 = 0; d1 < D; ++d1) {
+                std::fill(acc.begin(), acc.begin() + D, 0.0);
+                for (int j = 0; j < DH; ++j) {
+                    const double kk = (double)ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d1];
+                    const float* qr = &q->data[((size_t)h * DH + j) * D];
+                    for (int d = 0; d < D; ++d) acc[d] += kk * qr[d];
+                }
+                for (int d = 0; d < D; ++d) M[((size_t)h * D + d1) * D + d] = (float)acc[d];
+            }
+        for (int n = 0; n < 2 * D; ++n) {
+            std::fill(acc.begin(), acc.begin() + HD, 0.0);
+            for (int f = 0; f < inner; ++f) {
+                const double wn = wo->data[(size_t)n * inner + f];
+                const float* vr = &v->data[(size_t)f * D];
+                double* dst = &acc[(size_t)(f / DH) * D];
+                for (int d = 0; d < D; ++d) dst[d] += wn * vr[d];
+            }
+            for (int c2 = 0; c2 < HD; ++c2) WoF[(size_t)n * HD + c2] = (float)acc[c2];
+        }
+        if (int r = upload_T(&w->wqp, M)) return r;
+        return upload_T(&w->wo_f, interleave(WoF, D, HD, G));
+    }
+
     int load_attn(const std::string& p, int inner, bool cross, AttnW* w, std::vector<float>* kv_concat, int G) {
         const HostTensor *q = get(p + ".q.weight", {inner, D}), *k = get(p + ".k.weight", {inner, D}),
                          *v = get(p + ".v.weight", {inner, D}), *wo = get(p + ".fc_out.0.weight", {2 * D, inner}),
@@ -305,42 +351,14 @@ struct Engine : EngineBase {
                     for (int j = 0; j < DH; ++j) kT[((size_t)h * D + d) * DH + j] = ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d];   // (0.125: exact)
             if (int r = upload_T(&w->wkT, kT)) return r;
             if (int r = upload_T(&w->wv, v->data)) return r;
-            if (latent_fold()) {
-                // inner == 2 D (config.yml dims: 8 heads of 64 at width 256): both per-head projections fold into their neighbours at load
-                // time (products in double, rounded once to the storage type) and the sub-layer is THREE launches instead of five:
-                //   q'[h*D + d'] = sum_d z[d] * M[h*D + d'][d],   M = 0.125 Wk_h^T Wq_h            (in the LN-prologue GEMM, N = heads*D)
-                //   y[n]         = sum_{h,d} c[h*D + d] * Wo'[n][h*D + d],  Wo' = Wo[:, h] Wv_h     (in the gated output projection, K = heads*D)
-                const int H = inner / DH, HD = H * D;
-                std::vector<float> M((size_t)HD * D), WoF((size_t)2 * D * HD);
-                std::vector<double> acc(std::max(D, HD));
-                for (int h = 0; h < H; ++h)
-                    for (int d1 = 0; d1 < D; ++d1) {
-                        std::fill(acc.begin(), acc.begin() + D, 0.0);
-                        for (int j = 0; j < DH; ++j) {
-                            const double kk = (double)ATTN_SCALE * k->data[((size_t)h * DH + j) * D + d1];
-                            const float* qr = &q->data[((size_t)h * DH + j) * D];
-                            for (int d = 0; d < D; ++d) acc[d] += kk * qr[d];
-                        }
-                        for (int d = 0; d < D; ++d) M[((size_t)h * D + d1) * D + d] = (float)acc[d];
-                    }
-                for (int n = 0; n < 2 * D; ++n) {
-                    std::fill(acc.begin(), acc.begin() + HD, 0.0);
-                    for (int f = 0; f < inner; ++f) {
-                        const double wn = wo->data[(size_t)n * inner + f];
-                        const float* vr = &v->data[(size_t)f * D];
-                        double* dst = &acc[(size_t)(f / DH) * D];
-                        for (int d = 0; d < D; ++d) dst[d] += wn * vr[d];
-                    }
-                    for (int c2 = 0; c2 < HD; ++c2) WoF[(size_t)n * HD + c2] = (float)acc[c2];
-                }
-                if (int r = upload_T(&w->wqp, M)) return r;
-                if (int r = upload_T(&w->wo_f, interleave(WoF, D, HD, G))) return r;
-            }
+            if (latent_fold()) { if (int r = fold_latent(q, k, v, wo, inner, w, G)) return r; }
         } else {
             std::vector<float> cat(q->data);
             cat.insert(cat.end(), k->data.begin(), k->data.end());
             cat.insert(cat.end(), v->data.begin(), v->data.end());
             if (int r = upload_T(&w->wqkv, cat)) return r;
+            // decoder self attention in latent form (r05): the same two folds, against the history of normalised block inputs
+            if (G == 8 && latent_fold()) { if (int r = fold_latent(q, k, v, wo, inner, w, G)) return r; }
         }
         if (int r = upload_T(&w->wo, interleave(wo->data, D, inner, G))) return r;
         if (G != 16) {                                        // decoder: the prefill runs these projections on the encoder-side GEMMs
@@ -534,7 +552,17 @@ struct Engine : EngineBase {
         V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
         hybrid = c.embed == TXO_EMBED_HYBRID;
         {
-            const bool exists = (D == 64 && la_supported<T, 64>()) || (D == 256 && la_supported<T, 256>()) || (D == 768 && la_supported<T, 768>());
+            bool exists = (D == 64 && la_supported<T, 64>()) || (D == 256 && la_supported<T, 256>()) || (D == 768 && la_supported<T, 768>());
+            // the tile needs up to 145 KB of dynamic LDS: the opt-in is asked for HERE, and a refusal switches the latent form off for this
+            // engine (every decode then takes the K/V form) instead of surfacing as a failed launch in the middle of a generate
+            auto opt_in = [&](const void* kern, size_t lds) {
+                if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); exists = false; }
+            };
+            if (exists) {
+                if constexpr (la_supported<T, 64>()) { if (D == 64) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 64>), la_lds_bytes<T, 64>()); }
+                if constexpr (la_supported<T, 256>()) { if (D == 256) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 256>), la_lds_bytes<T, 256>()); }
+                if constexpr (la_supported<T, 768>()) { if (D == 768) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 768>), la_lds_bytes<T, 768>()); }
+            }
             latent_ok = exists;
         }
         Nmax = c.max_tokens > 0 ? c.max_tokens : 1 + (c.canvas_h / 16) * (c.canvas_w / 16);
@@ -566,6 +594,7 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dhid, (size_t)Bmax * Fmax)) return r;
         if (int r = dalloc(&dz, (size_t)Bmax * D)) return r;
         if (int r = dalloc(&dqt, (size_t)Bmax * Imax)) return r;
+        if (int r = dalloc(&zc, (size_t)c.dec_layers * Bmax * Tmax * D)) return r;
         if (int r = dalloc(&dqp, (size_t)Bmax * c.dec_heads * D)) return r;
         if (int r = dalloc(&dcl, (size_t)Bmax * c.dec_heads * D)) return r;
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
@@ -740,6 +769,7 @@ struct Engine : EngineBase {
         kmask_on = false;
         // a session opened through the C entry point steps with launches: it takes the form generate()'s launches take at this batch size
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
+        lat_self = false;
         if (!use_latent && project_kv) ensure_ckv(s);
         set_lanes(1, s);
         reset_lanes(s, eos);
@@ -791,7 +821,7 @@ struct Engine : EngineBase {
         const int bn = half ? 16 : DG_BN;
         const dim3 grid((a.N + bn - 1) / bn, (a.rows + DG_BM - 1) / DG_BM), blk(256);
         const size_t lds = dec_gemm_lds_bytes<T>(a.K, has_pro);
-        a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : (EPI == EPI_STORE_T ? "gemm LN+q (latent cross)" : "gemm LN+logits")))) : nullptr;
+        a.stamps = (grid.x * grid.y <= (unsigned)STAMP_BLOCKS) ? next_stamp(PRO == PRO_NONE ? (EPI == EPI_GLU_RES ? "gemm out-proj+GLU+res" : "gemm ffn-out+res") : (EPI == EPI_QKV ? "gemm LN+qkv" : (EPI == EPI_GEGLU ? "gemm LN+ffn-in+GeGLU" : (EPI == EPI_STORE_T ? "gemm LN+q' (latent)" : "gemm LN+logits")))) : nullptr;
         // K known at compile time for the shapes of the reference configurations (straight-line code, exact register
         // arrays); any other K takes the run-time form (KW = 0)
         constexpr int KCH = Elem<T>::KCHUNK;
@@ -926,6 +956,58 @@ struct Engine : EngineBase {
         GrpGemmArgs<T> g{A, lda, W, out, ldo, rows, N, NG};
         hipLaunchKernelGGL((grp_gemm_kernel<T, KG>), dim3((N + 63) / 64, (rows + 15) / 16), dim3(256), 0, s, g);
     }
+    // the latent core over lane li's rows: q' in dqp, c to dcl.  Cross attention: enc = the session's encoder rows of the lane's first image,
+    // len = sN, every beam of an image reads the same rows (kv_div).  Self attention: enc = the lane's rows of the z history of one layer,
+    // enc_rows = Tmax, len = position + 1 (host value or *t_ptr), kv_div = 1, path = the beams' slot tables (or null).
+    void launch_lat_core(hipStream_t s, int li, int kv_div, const T* enc, int len, int enc_rows, const int* t_ptr, const short* path,
+                         const char* stamp_name, bool cross) {
+        const Lane& ln = lanes[li];
+        const size_t r0 = ln.b0;
+        const int H = cfg.dec_heads, HD = H * D;
+        LatCoreArgs<T> a{};
+        a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc;
+        a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = len; a.kv_div = kv_div;
+        a.enc_rows = enc_rows; a.t_ptr = t_ptr; a.path = path; a.path_stride = Tmax;
+        int nimg = (ln.nb + kv_div - 1) / kv_div;
+        if (cross && kv_div > 1 && ln.nb % kv_div == 0 && lat_g_env == 0) {
+            // beam search: the k beams of an image read the SAME encoder rows, and their q' / c rows are contiguous ([rows][heads * D]) --
+            // one image = ONE row of k * heads heads, LA_GMAX of them per tile (the MFMA tile has 16 head columns whether 8 or 16 are
+            // used): 640 tiles of 8 heads become 384 of up to 16.  A head's bits do not depend on the grouping.
+            a.rows = nimg; a.heads = H * kv_div; a.G = LA_GMAX; a.ngrp = (a.heads + LA_GMAX - 1) / LA_GMAX; a.kv_div = 1;
+        }
+        const int nblk = ((nimg + 7) / 8) * 8 * a.kv_div * a.ngrp;   // XCD-aware tile order (lat_core_kernel)
+        a.stamps = (nblk <= STAMP_BLOCKS) ? next_stamp(stamp_name) : nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool timed = cross && (prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size()));
+        if (timed) { e0 = pool.next(); e1 = pool.next(); }
+#define TXO_LA(D_)                                                                                                           \
+        do {                                                                                                                 \
+            if constexpr (la_supported<T, D_>()) {                                                                           \
+                auto kern = lat_core_kernel<T, D_>;                                                                          \
+                const size_t lds = la_lds_bytes<T, D_>();                                                                    \
+                if (timed) hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, e0, e1, 0, a);       \
+                else hipLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, a);                            \
+            }                                                                                                                \
+        } while (0)
+        if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
+#undef TXO_LA
+        if (timed) ev_cross.push_back({e0, e1});
+    }
+    // self attention of layer l in latent form (folded weights): [embedding / LN sandwich + q' = z M^T, z appended to the history] ->
+    // [scores / values against the history of z]; the gated output projection (Wo' folded) follows in enqueue_step
+    int launch_lat_self(hipStream_t s, int li, int l, const BeamCtx* bm, const DecGemmArgs<T>& base) {
+        const Lane& ln = lanes[li];
+        const size_t r0 = ln.b0;
+        const int HD = cfg.dec_heads * D;
+        T* zl = zc + ((size_t)l * sB + r0) * Tmax * D;           // this lane's rows of layer l's history
+        DecGemmArgs<T> a = base; a.N = HD; a.K = D; a.W = dec_self[l].wqp; a.y = dy + r0 * D; a.x_out = dx + r0 * D;
+        a.tok = cur_tok + r0; a.tok_emb = tok_emb; a.pos_emb = pos_emb;
+        a.h_out = dqp + r0 * HD; a.F = HD; a.z_cache = zl;
+        if (int r = (l == 0 ? launch_dec_gemm<PRO_EMBED, EPI_STORE_T>(s, a) : launch_dec_gemm<PRO_LN2, EPI_STORE_T>(s, a))) return r;
+        launch_lat_core(s, li, 1, zl, step_host_t + 1, Tmax, step_host_t >= 0 ? nullptr : &st[li].t, bm ? bm->path_cur + r0 * Tmax : nullptr,
+                        "attn self (latent core)", false);
+        return 0;
+    }
     int launch_lat_cross(hipStream_t s, int li, int l, int kv_div, const DecGemmArgs<T>& base) {
         const Lane& ln = lanes[li];
         const size_t r0 = ln.b0;
@@ -944,36 +1026,8 @@ struct Engine : EngineBase {
             // 2. q'_h = q_h (0.125 Wk_h)
             launch_grp_gemm<DH>(s, dqt + r0 * Id, Id, dec_cross[l].wkT, dqp + r0 * HD, HD, ln.nb, HD, D);
         }
-        {   // 3. c_h = softmax_n(q'_h . enc[n]) enc
-            LatCoreArgs<T> a{};
-            a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc_t + (r0 / kv_div) * (size_t)sN * D;
-            a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = sN; a.kv_div = kv_div;
-            int nimg = (ln.nb + kv_div - 1) / kv_div;
-            if (kv_div > 1 && ln.nb % kv_div == 0 && lat_g_env == 0) {
-                // beam search: the k beams of an image read the SAME encoder rows, and their q' / c rows are contiguous ([rows][heads * D]) --
-                // one image = ONE row of k * heads heads, LA_GMAX of them per tile (the MFMA tile has 16 head columns whether 8 or 16 are
-                // used): 640 tiles of 8 heads become 384 of up to 16.  A head's bits do not depend on the grouping.
-                a.rows = nimg; a.heads = H * kv_div; a.G = LA_GMAX; a.ngrp = (a.heads + LA_GMAX - 1) / LA_GMAX; a.kv_div = 1;
-            }
-            const int nblk = ((nimg + 7) / 8) * 8 * a.kv_div * a.ngrp;   // XCD-aware tile order (lat_core_kernel)
-            a.stamps = (nblk <= STAMP_BLOCKS) ? next_stamp("attn cross (latent core)") : nullptr;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            const bool timed = prof || (prof_cross && (cross_seq++ & 3) == 0 && pool.used + 2 <= pool.ev.size());
-            if (timed) { e0 = pool.next(); e1 = pool.next(); }
-#define TXO_LA(D_)                                                                                                           \
-            do {                                                                                                             \
-                if constexpr (la_supported<T, D_>()) {                                                                       \
-                    auto kern = lat_core_kernel<T, D_>;                                                                      \
-                    const size_t lds = la_lds_bytes<T, D_>();                                                                \
-                    if (!la_attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); la_attr_set = true; } \
-                    if (timed) hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, e0, e1, 0, a);   \
-                    else hipLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, a);                        \
-                }                                                                                                            \
-            } while (0)
-            if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
-#undef TXO_LA
-            if (timed) ev_cross.push_back({e0, e1});
-        }
+        // 3. c_h = softmax_n(q'_h . enc[n]) enc
+        launch_lat_core(s, li, kv_div, enc_t + (r0 / kv_div) * (size_t)sN * D, sN, 0, nullptr, nullptr, "attn cross (latent core)", true);
         if (fold) return 0;                                       // 4+5: the gated output projection takes c directly (K = heads*D, Wo' folded at load)
         // 4. o_h = c_h Wv_h^T ; 'b h n d -> b n (h d)'
         if (D == 64) launch_grp_gemm<64>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
@@ -1001,7 +1055,14 @@ struct Engine : EngineBase {
         const size_t self_stride = (size_t)B * Id * Tmax, cross_stride = (size_t)sImg * N * Id;
         for (int l = 0; l < cfg.dec_layers; ++l) {
             T* kc = skv + (size_t)(2 * l) * self_stride; T* vc = skv + (size_t)(2 * l + 1) * self_stride;
-            {   // causal self attention
+            if (lat_self) {   // causal self attention against the history of normalised block inputs (lat_attn.h)
+                if (int r = launch_lat_self(s, li, l, bm, base)) return r;
+                dbg(s, "self attn (latent)", l);
+                DecGemmArgs<T> g = base; g.N = 2 * D; g.K = cfg.dec_heads * D; g.W = dec_self[l].wo_f; g.bias = dec_self[l].bo;
+                g.A = dcl + r0 * cfg.dec_heads * D; g.resid = lx; g.y_out = ly;
+                if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
+                dbg(s, "self out", l);
+            } else {   // causal self attention
                 AttnOpt o; o.W = dec_self[l].wqkv; o.K = kc; o.V = vc; o.lmax = Tmax; o.x_out = lx;
                 if (bm) o.path = bm->path_cur;
                 if (self_plain || bm || kmask_on) {
@@ -1109,7 +1170,7 @@ struct Engine : EngineBase {
     // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
     int lane_graph(int li, int eos) {
         Lane& ln = lanes[li];
-        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg && ln.glat == (int)use_latent) return 0;
+        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg && ln.glat == (int)use_latent + 2 * (int)lat_self) return 0;
         if (ln.exec) { (void)hipGraphExecDestroy(ln.exec); ln.exec = nullptr; }
         if (ln.graph) { (void)hipGraphDestroy(ln.graph); ln.graph = nullptr; }
         hipStream_t cs = cap_stream;
@@ -1119,7 +1180,7 @@ struct Engine : EngineBase {
         if (r) return r;
         if (e != hipSuccess) return fail(TXO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
         HIP_TRY(hipGraphInstantiate(&ln.exec, ln.graph, nullptr, nullptr, 0));
-        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg; ln.glat = (int)use_latent;
+        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg; ln.glat = (int)use_latent + 2 * (int)lat_self;
         return 0;
     }
 
@@ -1396,7 +1457,7 @@ struct Engine : EngineBase {
         if (persist_cooldown > 0) --persist_cooldown;
         if (persist_usable(B)) {
             int steps = 0;
-            use_latent = false;
+            use_latent = false; lat_self = false;
             ensure_ckv(s);
             bool broke = false;
             const int pr = generate_persist(B, N, n_pos, max_len, eos, tokens_out, logits_out, &steps, &broke, s);
@@ -1423,6 +1484,7 @@ struct Engine : EngineBase {
         // graph replay by default only for very small batches (B <= 4: there the host's enqueue rate bounds the step --
         // 34.2 vs 37.2 ms per generate at B = 1 -- from B = 8 on it is equal); TXO_GRAPH=1 / 0 forces it on / off
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
+        lat_self = use_latent && lat_self_ok();
         if (!use_latent) ensure_ckv(s);
         const char* genv = getenv("TXO_GRAPH");
         const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
@@ -1554,6 +1616,7 @@ struct Engine : EngineBase {
         }
         if (int r = begin_session(enc, B, N, eos, s, false)) return r;
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(rows)));
+        lat_self = use_latent && lat_self_ok();
         if (!use_latent) ensure_ckv(s);                               // cross K/V of the B images
         sB = rows; sImg = B;                                          // decode rows are (image, beam) slots
         last_persist = false;

@@ -40,14 +40,21 @@
 namespace txo {
 
 constexpr int LA_GMAX = 16;               // heads per tile = columns of the MFMA tile
+constexpr int LA_PATH_TILES = 4;          // beam search, self attention: key tiles per wave whose slots are looked up (8 waves: 512 positions)
 
 template <typename T> struct LatCoreArgs {
     const T* qp;                          // [rows][heads*D]   q' (already scaled)
     const T* enc;                         // [images][len][D]
     T* c;                                 // [rows][heads*D]   normalised sum_n p[n] enc[n]
     int rows, heads, G, ngrp;             // heads per tile, tiles per row = ceil(heads / G)
-    int len;                              // encoder tokens
+    int len;                              // keys: encoder tokens (cross) / decoded positions t + 1 (self, when the host knows t)
     int kv_div;                           // beam search: encoder image = row / kv_div
+    // SELF attention in latent form (r05): `enc` is the history of normalised block inputs z, [rows][enc_rows][D] with enc_rows = the
+    // positional table's length; keys 0 .. t.  t_ptr: the device-side position counter (graph replay: len = *t_ptr + 1), or null.
+    // path: beam search -- position p of row r lives in slot path[r * path_stride + p] (the current position in the row's own slot), or null.
+    int enc_rows;                         // rows per image of `enc` (0 = len)
+    const int* t_ptr;
+    const short* path; int path_stride;
     unsigned long long* stamps;           // diagnostic: per tile {entry, last key tile done, exit}
 };
 
@@ -107,9 +114,21 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
         if (h >= nh) qreg[i] = u32x4{0u, 0u, 0u, 0u};
     }
     const int kvimg = img / a.kv_div;
-    const T* eb = a.enc + (size_t)kvimg * a.len * D_;
-    const int ntiles = (a.len + 15) >> 4, nt_w = (ntiles + NW - 1) / NW;
-    const int last_key = a.len - 1;
+    const int len = a.t_ptr ? *a.t_ptr + 1 : a.len;
+    const int erows = a.enc_rows ? a.enc_rows : len;
+    const T* eb = a.enc + (size_t)kvimg * erows * D_;
+    const int ntiles = (len + 15) >> 4, nt_w = (ntiles + NW - 1) / NW;
+    const int last_key = len - 1;
+    // beam search: the slots of this lane's keys (tile it of this wave: key 16 * (wave + it * NW) + lc), fetched before any encoder
+    // row so that no row request waits behind a slot lookup; LA_PATH_TILES tiles per wave cover the positional table (engine.hip checks)
+    short slot[LA_PATH_TILES];
+    if (a.path) {
+#pragma unroll
+        for (int it = 0; it < LA_PATH_TILES; ++it) {
+            const int key = min((wave + it * NW) * 16 + lc, last_key);
+            slot[it] = key == last_key ? (short)img : a.path[(size_t)img * a.path_stride + key];
+        }
+    }
     // NF: tiles requested AHEAD of the one being consumed (registers: KC x 4 per tile), NF + 1 statically named register
     // sets used round-robin.  Every request is unconditional (a branch around the refill made hipcc wait vmcnt(0) before every
     // tile, so each tile paid the full latency of the refill issued just before it; rotating the sets through copies forces
@@ -120,6 +139,12 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
     auto issue = [&](int it, u32x4 (&dst)[KC]) {              // `it`-th tile of this wave: keys 16 * (wave + it * NW) ..
         const int key = min((wave + it * NW) * 16 + lc, last_key);
         const T* p = eb + (size_t)key * D_ + lg * PER16;
+        if (a.path) {                                         // (wave-uniform branch; the slot by a select chain: no run-time register indexing)
+            int sl = img;                                     // tiles past the table clamp to the last key, which lives in the row's own slot
+#pragma unroll
+            for (int j = 0; j < LA_PATH_TILES; ++j) sl = it == j ? (int)slot[j] : sl;
+            p = a.enc + ((size_t)sl * erows + key) * D_ + lg * PER16;
+        }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) dst[kc] = ld16(p + kc * KCH);
     };
