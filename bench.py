@@ -55,6 +55,16 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(dims, sd_np, a):
     """The reference algorithm on the host CPU through the oracle (oracle/cpu_ref.py), on the SAME workload (64 images,
     256 greedy steps), bounded to tens of seconds by sampling:
@@ -134,7 +144,10 @@ def cpu_baseline(dims, sd_np, a):
                       f"lengths {ts} ({', '.join(f'{c:.2f}' for c in cost)} s) and interpolated over the {T} steps: {measured:.1f} s of CPU "
                       f"work measured, {total:.0f} s estimated for the whole batch; torch CPU fp32, {best_nt} threads (fastest on the real "
                       f"{B}-image step at prefix length {xp.shape[1]}: seconds by thread count {probe}) on {ncpu} logical CPUs; "
-                      f"validated once against the whole un-sampled batch (profiles/r03_cpu_baseline_full.json: 246.8 s = 0.259 images/s)",
+                      f"THIS host's estimate (the figure is per host: driver boxes of rounds 3 and 4 gave 0.267 and 0.502 images/s); the "
+                      f"interpolation was validated once, on a 2 x EPYC 9575F GPU box, against the whole un-sampled batch "
+                      f"(profiles/r03_cpu_baseline_full.json: 246.8 s = 0.259 images/s where that box's sampled estimate was 0.26-0.27)",
+            "host": {"logical_cpus": int(ncpu), "cpu_model": _cpu_model()},
             "cached": {"value": round(bc / dtc, 3), "unit": "images/sec",
                        "sample": f"oracle KV-cached mode, {bc} images, all {T} steps, {dtc:.1f} s wall"}}
     if full:

@@ -154,6 +154,8 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
 #define TXO_Q_PERSIST_FALLBACKS 1
 #define TXO_Q_LAST_ROW_RANGES 2   /* row ranges (streams) the last generate decoded on: 1, or 2 beyond 128 images in bf16 (launch path) */
 #define TXO_Q_LAST_LATENT 3       /* 1 if the last generate's cross attention ran in latent form (csrc/lat_attn.h: against the raw encoder rows) */
+#define TXO_Q_RELOAD_KNOBS 4      /* not a question: re-read the TXO_* development knobs of generate() from the environment (the engine reads them once,
+                                   * at creation; tests flip TXO_PERSIST / TXO_LANES on a live engine).  *out = 0 */
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out);
 
 const char* txo_last_error(void);

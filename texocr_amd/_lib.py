@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtexocr_hip.so")
+# TXO_LIB_PATH: load ANOTHER build of the library (development only: probes/ab_libs.sh compares builds on one GPU box without
+# overwriting the in-tree product library)
+LIB_PATH = os.environ.get("TXO_LIB_PATH") or os.path.join(_HERE, "libtexocr_hip.so")
 
 TXO_F32, TXO_BF16 = 0, 1
 TXO_E_INVALID, TXO_E_STATE, TXO_E_HIP = -1, -2, -3

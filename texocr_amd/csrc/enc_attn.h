@@ -29,10 +29,14 @@ __device__ inline int swz256(int row, int piece) { return row * 256 + ((piece ^ 
 // (round-robin dispatch), so the nq query blocks of ONE (image, head) go to ONE XCD and its L2 fetches that head's K / V panel once for
 // all of them.  (With the (query block, batch*head) grid the five query blocks of a head landed on five XCDs: every K / V panel crossed
 // the fabric five times -- 2.3 GB per ViT-Base layer in 0.44 ms, i.e. the attention kernel was at the fabric's rate, not the VALU's.)
-__device__ inline bool ea_block(int nq, int nbh, int& bh, int& qb) {
+// rev: the (image, head) pairs in descending order (engine.hip: the encoder's kernels walk the rows alternately up and down, so that
+// each starts on what the previous one wrote last)
+__device__ inline bool ea_block(int nq, int nbh, int& bh, int& qb, int rev = 0) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     bh = (slot / nq) * 8 + xcd; qb = slot - (slot / nq) * nq;
-    return bh < nbh;
+    if (bh >= nbh) return false;
+    if (rev) bh = nbh - 1 - bh;
+    return true;
 }
 inline dim3 ea_grid(int nq, int nbh) { return dim3(((nbh + 7) / 8) * 8 * nq); }
 
@@ -420,12 +424,12 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restri
 // q,k,v: bf16 head-major [B*heads][N][64].  Bound: MFMA bf16 / softmax VALU, about equal.
 template <typename TO>
 __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
-                                                               const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads, int nbh) {
+                                                               const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads, int nbh, int rev) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 128];   // [buf][K | V], 128-byte rows
     static_assert(sizeof(lds) >= 4 * 32 * 64 * 4, "epilogue tile must fit");
     typedef short s16x4 __attribute__((ext_vector_type(4)));
     int bh, qblk;
-    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk)) return;
+    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk, rev)) return;
     const int b = bh / heads, head = bh - b * heads;
     const int q0 = qblk * EA_QBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

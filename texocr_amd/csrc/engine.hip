@@ -145,6 +145,30 @@ struct Engine : EngineBase {
     };
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
+    // Run-time knobs of generate() (development / test switches).  Read ONCE per engine, at creation; txo_engine_query(TXO_Q_RELOAD_KNOBS)
+    // reads them again (the Python binding does that when it sees the TXO_* environment change between two calls: tests flip
+    // TXO_PERSIST / TXO_LANES on a live engine).  Everything else in this struct's neighbourhood is read once, in the member initialisers.
+    struct RunKnobs {
+        int persist = -1, graph = -1, lanes = 0;        // -1 / 0 = unset
+        bool stamps = false, pstamps = false, lat_nofold = false;
+        std::string stamps_file, pstamps_file;
+        int stagger_ticks = 0, poll_sleep = 1, early_mask = 0, poll_mode = 3, inject_fail = 0;
+        bool has_stagger = false, has_early = false, has_inject = false;
+        void read() {
+            *this = RunKnobs{};
+            if (const char* e = getenv("TXO_PERSIST")) persist = atoi(e) != 0;
+            if (const char* e = getenv("TXO_GRAPH")) graph = atoi(e) != 0;
+            if (const char* e = getenv("TXO_LANES")) lanes = std::max(1, atoi(e));
+            if (const char* e = getenv("TXO_STAMPS")) { stamps = true; stamps_file = e; }
+            if (const char* e = getenv("TXO_PSTAMPS")) { pstamps = true; pstamps_file = e; }
+            lat_nofold = getenv("TXO_LAT_NOFOLD") != nullptr;
+            if (const char* e = getenv("TXO_PS_STAGGER_US")) { has_stagger = true; stagger_ticks = (int)(atof(e) * 100.0); }
+            if (const char* e = getenv("TXO_PS_POLL_SLEEP")) poll_sleep = atoi(e);
+            if (const char* e = getenv("TXO_PS_EARLY")) { has_early = true; early_mask = atoi(e); }
+            if (const char* e = getenv("TXO_PS_POLL")) poll_mode = atoi(e);
+            if (const char* e = getenv("TXO_PERSIST_INJECT_FAIL")) { has_inject = true; inject_fail = atoi(e); }
+        }
+    } knobs;
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
@@ -160,6 +184,7 @@ struct Engine : EngineBase {
     // latent_ok: the tile exists for this engine's width / storage type.  lat_mode (TXO_LATENT, read once): 1 = every decode runs with
     // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
     bool latent_ok = false, use_latent = false;
+    int n_cus = 256;                  // compute units of this engine's device (init): one latent tile per CU is the grouping target
     // lat_self: this session's SELF attention also runs in latent form (the history is z, not k / v: a quarter of the bytes at config.yml
     // dims).  Only inside generate() / generate_beam() with launches in latent form: a session opened through txo_decode_begin may be
     // prefilled or masked, which work on the K/V history.  OPT-IN (TXO_LATENT_SELF=1, read once per engine): measured on MI355X it
@@ -175,6 +200,7 @@ struct Engine : EngineBase {
     int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
+    int enc_walk = getenv("TXO_ENC_WALK") ? atoi(getenv("TXO_ENC_WALK")) : 1;   // encoder kernels walk the rows alternately up and down (encode()); 0 = all upwards
     int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
@@ -528,6 +554,7 @@ struct Engine : EngineBase {
     }
 
     int init() {
+        knobs.read();
         arena = Arena{}; arena.measuring = true;
         if (int r = init_buffers()) return r;                 // pass 1: sizes only
         if (int r = arena_begin(arena.off)) return r;
@@ -551,6 +578,10 @@ struct Engine : EngineBase {
         D = c.embed_dim; Ie = c.enc_heads * DH; Id = c.dec_heads * DH; Fe = c.enc_exp * D; Fd = c.dec_exp * D;
         V = c.vocab; Tmax = c.max_len; Bmax = c.max_batch;
         hybrid = c.embed == TXO_EMBED_HYBRID;
+        {
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+        }
         {
             bool exists = (D == 64 && la_supported<T, 64>()) || (D == 256 && la_supported<T, 256>()) || (D == 768 && la_supported<T, 768>());
             // the tile needs up to 145 KB of dynamic LDS: the opt-in is asked for HERE, and a refusal switches the latent form off for this
@@ -617,20 +648,20 @@ struct Engine : EngineBase {
 
     // ------------------------------------------------------------------------------------------
     template <int MODE, typename TZ>
-    void launch_ln(hipStream_t s, const float* in, float* x_out, TZ* z_out, const float* g, const float* b, int rows) {
+    void launch_ln(hipStream_t s, const float* in, float* x_out, TZ* z_out, const float* g, const float* b, int rows, int rev = 0) {
         const dim3 grid((rows + 3) / 4), blk(256);
-        if (D == 256) hipLaunchKernelGGL((ln_rows_kernel<TZ, 1, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
-        else if (D == 512) hipLaunchKernelGGL((ln_rows_kernel<TZ, 2, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
-        else if (D == 768) hipLaunchKernelGGL((ln_rows_kernel<TZ, 3, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows);
+        if (D == 256) hipLaunchKernelGGL((ln_rows_kernel<TZ, 1, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, rev);
+        else if (D == 512) hipLaunchKernelGGL((ln_rows_kernel<TZ, 2, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, rev);
+        else if (D == 768) hipLaunchKernelGGL((ln_rows_kernel<TZ, 3, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, rev);
         else hipLaunchKernelGGL((ln_rows_generic_kernel<TZ, MODE>), grid, blk, 0, s, in, x_out, z_out, g, b, rows, D);
     }
 
     // C = A * W^T with A plain row-major [M][K]: the 256x256 LDS-DMA kernel (gemm_pp.h) for bf16 shapes it fits, else the
     // 128x128 register-staged kernel.  TXO_GEMM_OLD=1 forces the latter (tests compare the two bit for bit).
     template <class Epi>
-    void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi) {
+    void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi, int rev = 0) {
         if constexpr (sizeof(T) == 2) {
-            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr); return; }
+            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr, rev); return; }
         }
         launch_gemm_big<T>(s, LoadPlain<T>{A, K}, W, M, N, K, epi);
     }
@@ -717,6 +748,12 @@ struct Engine : EngineBase {
             gemm_plain(s, feat, patch_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
         }
         const size_t hs = (size_t)M * Ie;      // one of q/k/v, head-major [B*heads][N][64]
+        // Walk direction (perf mode, enc_walk): successive kernels of the stack walk the rows alternately upwards and downwards, so that each
+        // starts on the rows its producer wrote LAST -- still in the 256 MB Infinity Cache -- instead of on the ones it wrote first
+        // (every intermediate here is 0.2-0.9 GB at batch 256: with all kernels walking upwards a consumer's first reads are the
+        // producer's oldest lines).  Results do not depend on it (every kernel's rows are independent).
+        bool down = false;                                    // direction of the NEXT kernel
+        auto dir = [&]() -> int { if (!enc_walk || sizeof(T) != 2) return 0; const bool d = down; down = !down; return d ? 1 : 0; };
         for (int l = 0; l < cfg.enc_layers; ++l) {
             // The stream between two sub-layers is x = LN(y) (the residual) and z = LN(x) (the block input), attention.py:242-259.
             // x is never written: the row kernel leaves {mean, rstd} of LN(y) per row (rows.h MODE 3) and the next GEMM epilogue
@@ -724,8 +761,8 @@ struct Engine : EngineBase {
             const ResidLN res_x{ey, estats, enc_gb, D}, res_first{ex, nullptr, nullptr, D};
             // outputs far beyond the caches are written non-temporally (they would evict the GEMM's own operand panels from L2)
             const int nt_y = enc_nt((size_t)M * D * 4), nt_qkv = enc_nt((size_t)3 * M * Ie * sizeof(T)), nt_h = enc_nt((size_t)M * Fe * sizeof(T));
-            if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M);
-            else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
+            if (l == 0) launch_ln<0, T>(s, ex, nullptr, ez, enc_g, enc_b, M, dir());
+            else launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M, dir());
             const dim3 agrid = ea_grid((N + EA_QBLK - 1) / EA_QBLK, B * cfg.enc_heads);   // XCD-aware block order (enc_attn.h: ea_block)
             const int nbh = B * cfg.enc_heads;
             if constexpr (sizeof(T) == 4) {
@@ -736,17 +773,17 @@ struct Engine : EngineBase {
             } else {                                              // perf mode: bf16 q/k/v, bf16 MFMA attention
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
-                                   EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N, nt_qkv});
-                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh);
+                                   EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N, nt_qkv}, dir());
+                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh, dir());
                 else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh);
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
-                               EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo, nt_y});
-            launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M);
-            gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe, nt_h});
-            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2, nt_y});
+                               EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo, nt_y}, dir());
+            launch_ln<3, T>(s, ey, estats, ez, enc_g, enc_b, M, dir());
+            gemm_plain(s, ez, enc_mlp[l].w1, M, 2 * Fe, D, EpiGeglu<T>{ehid, enc_mlp[l].b1, Fe, nt_h}, dir());
+            gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2, nt_y}, dir());
         }
-        launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M);
+        launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M, dir());
         if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -768,7 +805,10 @@ struct Engine : EngineBase {
         ckv_valid = false;
         kmask_on = false;
         // a session opened through the C entry point steps with launches: it takes the form generate()'s launches take at this batch size
-        use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
+        // A session opened through txo_decode_begin (project_kv) may be prefilled, and the multi-position forward works on the projected
+        // K/V panels: such a session steps in the K/V form too (one-pass and stepwise logits of decoder.net() then come from the same
+        // weights), unless TXO_LATENT=1 pins the latent form.  generate() / generate_beam() choose their form themselves.
+        use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && !project_kv && auto_latent(B)));
         lat_self = false;
         if (!use_latent && project_kv) ensure_ckv(s);
         set_lanes(1, s);
@@ -786,6 +826,20 @@ struct Engine : EngineBase {
         ckv_valid = true;
     }
 
+    // Error exit of a decode loop that forked onto the lanes' own streams: kernels of the failed call may still be running there on this
+    // engine's buffers.  The caller's stream is made to wait for every lane, drained, and the engine goes back to one lane; the error
+    // code passes through.
+    int abandon_lanes(hipStream_t s, int rc) {
+        for (int i = 1; i < n_lanes; ++i) {
+            if (hipEventRecord(ev_join[i], lanes[i].stream) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join[i], 0);
+            else (void)hipStreamSynchronize(lanes[i].stream);
+        }
+        (void)hipStreamSynchronize(s);
+        (void)hipGetLastError();
+        set_lanes(1, s);
+        stamp_slot = -1;
+        return rc;
+    }
     // split the batch into n contiguous row ranges (multiples of 16 rows where possible)
     void set_lanes(int n, hipStream_t s) {
         const int tiles = (sB + 15) / 16;
@@ -937,7 +991,7 @@ struct Engine : EngineBase {
     // (row, head group) tile per CU the latent tile moves 493 KB per CU against 300 KB and is slower, 19 vs 16 us per launch at batch
     // 64); wide decoders (768: the in-tile projections' weights are 3.4 MB per row) and the fp32 parity mode keep the K/V form.
     // the latent form's two per-head projections fold into their neighbouring GEMMs (load_attn) where the folded weights stay small
-    bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D && getenv("TXO_LAT_NOFOLD") == nullptr; }
+    bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D && !knobs.lat_nofold; }
     bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY; }
     // heads per latent tile: the smallest group that leaves at most one tile per CU for `rows` rows (fewer tiles = fewer
     // re-reads of an image's encoder rows; more tiles = more CUs pulling).  A head's bits do not depend on it.
@@ -946,7 +1000,7 @@ struct Engine : EngineBase {
         if (lat_g_env > 0) return std::min(std::min(H, LA_GMAX), lat_g_env);
         for (int g = 2; g < std::min(H, LA_GMAX); g *= 2)
             if (rows * ((H + g - 1) / g) <= slots) return g;
-        const int n = (H + LA_GMAX - 1) / LA_GMAX;            // as few tiles per row as the tile allows, evenly filled (12 heads: 6 + 6)
+        const int n = (H + LA_GMAX - 1) / LA_GMAX;            // as few tiles per row as the tile allows, evenly filled (12 heads: one tile of 12; 24: 12 + 12)
         return (H + n - 1) / n;
     }
     // cross attention of layer l in latent form (lat_attn.h): [LN sandwich + q] -> [q' per head] -> [scores / values against the raw
@@ -966,7 +1020,7 @@ struct Engine : EngineBase {
         const int H = cfg.dec_heads, HD = H * D;
         LatCoreArgs<T> a{};
         a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc;
-        a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, 256); a.ngrp = (H + a.G - 1) / a.G; a.len = len; a.kv_div = kv_div;
+        a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, n_cus); a.ngrp = (H + a.G - 1) / a.G; a.len = len; a.kv_div = kv_div;
         a.enc_rows = enc_rows; a.t_ptr = t_ptr; a.path = path; a.path_stride = Tmax;
         int nimg = (ln.nb + kv_div - 1) / kv_div;
         if (cross && kv_div > 1 && ln.nb % kv_div == 0 && lat_g_env == 0) {
@@ -1301,12 +1355,12 @@ struct Engine : EngineBase {
     bool persist_usable(int B) const {
         // sampling: the persistent kernel's sampler keeps a row in registers, 16 logits per lane (step.h: sample_row_regs)
         if (sample_mode && V > 64 * SR_PER) return false;
-        if (prof || prof_cross || g_dbg || getenv("TXO_STAMPS") || getenv("TXO_GRAPH") || getenv("TXO_LANES")) return false;
+        if (prof || prof_cross || g_dbg || knobs.stamps || knobs.graph >= 0 || knobs.lanes > 0) return false;
         if (cfg.dec_exp != 4 || cfg.dec_layers > PS_MAXLD) return false;
         const bool exists = (D == 256 && cfg.dec_heads == 8) || (D == 768 && cfg.dec_heads == 12 && sizeof(T) == 2);
         if (!exists) return false;
         if (latent_ok && lat_mode == 1) return false;           // latent form forced: the persistent kernel reads projected K/V panels
-        if (const char* pe = getenv("TXO_PERSIST")) return atoi(pe) != 0;
+        if (knobs.persist >= 0) return knobs.persist != 0;
         if (persist_cooldown > 0) return false;                // it gave up twice in a row (not all 256 workgroups co-resident?): not tried for a while
         if (D != 256) return false;                            // the 768-wide variant is opt-in (TXO_PERSIST=1): not measured faster
         // bf16 beyond 128 images: launches with the cross attention in latent form (one row range, two from 224 rows on) are ahead of the
@@ -1354,15 +1408,13 @@ struct Engine : EngineBase {
         pa.tokens_out = tokens_out; pa.out_stride = out_stride; pa.logits_out = logits_out;
         pa.sample = sample_mode; pa.sample_topk = sample_topk; pa.inv_temp = 1.0f / sample_temp; pa.seed = sample_seed;
         pa.ctl = pctl; pa.stamps = pstamps;
-        const char* stamp_file = getenv("TXO_PSTAMPS");
+        const char* stamp_file = knobs.pstamps ? knobs.pstamps_file.c_str() : nullptr;
         pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
-        if (const char* sg = getenv("TXO_PS_STAGGER_US")) pa.stagger_ticks = (int)(atof(sg) * 100.0);
-        pa.poll_sleep = 1;
-        if (const char* ps = getenv("TXO_PS_POLL_SLEEP")) pa.poll_sleep = atoi(ps);
-        if (const char* em = getenv("TXO_PS_EARLY")) pa.early_mask = atoi(em);
-        pa.poll_mode = 3;                                         // scalar polls behind s_dcache_inv (persist.h: TeamSync::poll; -1.3 % per generate against vector polls)
-        if (const char* pm = getenv("TXO_PS_POLL")) pa.poll_mode = atoi(pm);
-        if (const char* inj = getenv("TXO_PERSIST_INJECT_FAIL")) pa.inject_fail = atoi(inj);   // tests: the give-up / fall-back path
+        if (knobs.has_stagger) pa.stagger_ticks = knobs.stagger_ticks;
+        pa.poll_sleep = knobs.poll_sleep;
+        if (knobs.has_early) pa.early_mask = knobs.early_mask;
+        pa.poll_mode = knobs.poll_mode;                           // default 3: scalar polls behind s_dcache_inv (persist.h: TeamSync::poll; -1.3 % per generate against vector polls)
+        if (knobs.has_inject) pa.inject_fail = knobs.inject_fail; // tests: the give-up / fall-back path
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
         if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));
         if (D == 256) { if (int r = launch_persist<256, 8>(pa, s)) return r; }
@@ -1486,8 +1538,7 @@ struct Engine : EngineBase {
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
         lat_self = use_latent && lat_self_ok();
         if (!use_latent) ensure_ckv(s);
-        const char* genv = getenv("TXO_GRAPH");
-        const bool want_graph = genv ? atoi(genv) != 0 : B <= 4;
+        const bool want_graph = knobs.graph >= 0 ? knobs.graph != 0 : B <= 4;
         const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
         // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
         // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765).  Greedy and sampled alike: a draw is keyed
@@ -1498,7 +1549,7 @@ struct Engine : EngineBase {
         // in latent form the second range pays from ~224 rows on (160: 66.6 ms with one range vs 71.7 with two, 192: 70.6 vs 72.2, 256: 82.0 vs 77.9;
         // K/V form: two ranges from 129 on, 160: 70.9 vs 66.3)
         if (want == 2 && use_latent && D < 512 && B < 224) want = 1;
-        if (const char* e = getenv("TXO_LANES")) want = std::min(atoi(e), max_lanes);
+        if (knobs.lanes > 0) want = std::min(knobs.lanes, max_lanes);
         if (B < 32) want = 1;
         set_lanes(want, s);
         last_ranges = n_lanes;
@@ -1532,9 +1583,10 @@ struct Engine : EngineBase {
             pend_lo = -1;
             return false;
         };
-        const char* stamp_file = getenv("TXO_STAMPS");
+        const char* stamp_file = knobs.stamps ? knobs.stamps_file.c_str() : nullptr;
         if (stamp_file && !stamp_buf) { if (int r = dalloc(&stamp_buf, (size_t)STAMP_KERNELS * STAMP_BLOCKS * 3)) return r; }
         const int stamp_step = stamp_file ? std::min(n_pos - 1, 200) : -1;
+        auto decode_loop = [&]() -> int {
         for (int t = 0; t < n_pos; ++t) {
             if (t == stamp_step) { HIP_TRY(hipMemsetAsync(stamp_buf, 0, sizeof(unsigned long long) * STAMP_KERNELS * STAMP_BLOCKS * 3, s)); stamp_slot = 0; stamp_names.clear(); }
             else if (stamp_slot >= 0) dump_stamps(stamp_file, s);
@@ -1555,6 +1607,9 @@ struct Engine : EngineBase {
                 if (t + 1 == n_pos) { (void)look(); if (look_failed) return TXO_E_HIP; }
             }
         }
+        return 0;
+        };
+        if (int r = decode_loop()) return abandon_lanes(s, r);
         // join the lanes back into the caller's stream
         for (int i = 1; i < n_lanes; ++i) {
             HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
@@ -1625,7 +1680,7 @@ struct Engine : EngineBase {
         // launches run beside the other's HBM-bound attention launches.  A range is a whole number of IMAGES (beam_select_kernel ranks
         // an image's k beams together; self-attention slots are range-local); every range has its own step state and done flags.
         int want = (rows >= 256 && B >= 2 && !prof && !prof_cross && !g_dbg) ? 2 : 1;
-        if (const char* e = getenv("TXO_LANES")) want = std::max(1, std::min(std::min(atoi(e), max_lanes), B));
+        if (knobs.lanes > 0) want = std::max(1, std::min(std::min(knobs.lanes, max_lanes), B));
         if (want > 1) {
             n_lanes = want;
             int img0 = 0;
@@ -1663,6 +1718,7 @@ struct Engine : EngineBase {
             }
             pend_lo = -1;
         };
+        auto beam_loop = [&]() -> int {
         for (int t = 0; t < max_len && !stop; ++t) {
             BeamCtx bm{beams, bpath[cur], bpath[cur ^ 1]};
             for (int i = 0; i < n_lanes; ++i)
@@ -1689,6 +1745,9 @@ struct Engine : EngineBase {
                 if (look_err) return fail(TXO_E_HIP, "beam search: waiting for the done flags failed");
             }
         }
+        return 0;
+        };
+        if (int r = beam_loop()) { sB = B; return abandon_lanes(s, r); }
         for (int i = 1; i < n_lanes; ++i) {                           // join the ranges back into the caller's stream
             HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
             HIP_TRY(hipStreamWaitEvent(s, ev_join[i], 0));
@@ -1715,6 +1774,7 @@ struct Engine : EngineBase {
         else if (what == TXO_Q_PERSIST_FALLBACKS) *out = persist_fallbacks;
         else if (what == TXO_Q_LAST_ROW_RANGES) *out = last_persist ? 1 : last_ranges;
         else if (what == TXO_Q_LAST_LATENT) *out = (!last_persist && use_latent) ? 1 : 0;
+        else if (what == TXO_Q_RELOAD_KNOBS) { knobs.read(); *out = 0; }
         else return fail(TXO_E_INVALID, "unknown query");
         return 0;
     }

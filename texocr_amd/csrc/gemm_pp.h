@@ -60,7 +60,7 @@ __device__ unsigned long long g_pp_dbg[4096];      // probes/pp_bench.hip: block
 // no LDS (comment at the epilogue below).  TR = false is the LDS-staged epilogue (kept for A/B: TXO_PP_TR=0, probes/pp_epi_bench.hip).
 template <class Epi, bool TR>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                                int K, int tiles_n, int n_tiles, int ct, Epi epi) {
+                                                                int K, int tiles_n, int n_tiles, int ct, int rev, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];     // ONE array: [buf][A|W][row*128] + epilogue staging
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
         const int L = tile_seq(seq);
         const int band = L / band_tiles, k = L - band * band_tiles;
         const int cols = min(ct, tiles_n - band * ct);                                   // the last band may be narrower
-        const int row = k / cols, col = k - row * cols;
+        int row = k / cols; const int col = k - row * cols;
+        if (rev) row = tiles_m - 1 - row;                                                // the row panels top down (engine.hip: encode)
         m0 = row * PP_BM; n0 = (band * ct + col) * PP_BN;
     };
 
@@ -381,7 +382,7 @@ inline bool gemm_pp_fits(int M, int N, int K) {
 // The engine reads TXO_PP_TR once per engine and passes it here (tests build engines with each form and compare them bit for bit).
 
 template <class Epi, bool TR>
-inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi) {
+inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int rev) {
     const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
     const int n_tiles = tiles_m * tiles_n;
     // persistent grid: one block per CU (128-160 KiB LDS each).  Both the CU count and the > 64 KiB dynamic-LDS opt-in are per
@@ -409,12 +410,12 @@ inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M,
     if (ct_env > 0) ct = std::max(1, std::min(tiles_n, ct_env));
     // narrower last band: when tiles_n % ct != 0 the row-major walk of the last band uses its own width (tile_origin)
     const int grid = ((std::min(n_tiles, cus) + 7) / 8) * 8;
-    hipLaunchKernelGGL((gemm_pp_kernel<Epi, TR>), dim3(grid), dim3(PP_THREADS), smem, s, A, W, M, N, K, tiles_n, n_tiles, ct, epi);
+    hipLaunchKernelGGL((gemm_pp_kernel<Epi, TR>), dim3(grid), dim3(PP_THREADS), smem, s, A, W, M, N, K, tiles_n, n_tiles, ct, rev, epi);
 }
 template <class Epi>
-inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1) {
+inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1, int rev = 0) {
     if (tr < 0) tr = Epi::HAS_ROW ? 0 : 1;
-    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi);
+    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi, rev); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi, rev);
 }
 
 }  // namespace txo

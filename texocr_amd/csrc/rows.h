@@ -55,10 +55,13 @@ template <> __device__ inline void store4<bf16>(bf16* p, const float4& v) {
 template <typename T, int NV, int MODE>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const float* __restrict__ in, float* __restrict__ x_out,
                                                       T* __restrict__ z_out, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, int rows) {
+                                                      const float* __restrict__ beta, int rows, int rev) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
+    // rev: rows in descending order -- the rows a GEMM wrote LAST (highest: its tiles walk the row panels upwards) are read first, while
+    // they are still in the Infinity Cache, and the first rows of z, which the next GEMM reads first, are written last
+    if (rev) row = rows - 1 - row;
     constexpr int D = NV * 256;
     const float inv_d = 1.0f / D;
     float4 v[NV], g[NV], b[NV];

@@ -89,6 +89,11 @@ class HipEngine:
             _lib.check(self.lib.txo_engine_create(C.byref(cfg), C.byref(h)))
         self.handle = h
         self.loaded = False
+        self._env_seen = self._txo_env()             # what the engine saw when it read its knobs
+
+    @staticmethod
+    def _txo_env():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("TXO_")))
 
     def __del__(self):
         h = getattr(self, "handle", None)
@@ -132,6 +137,12 @@ class HipEngine:
     def _ensure(self) -> None:
         if (self._stale or not self.loaded) and self._provider is not None:
             self.load_state_dict(self._provider())
+        # the engine reads its TXO_* development knobs once, at creation; if the environment changed since the last call (tests
+        # flip TXO_PERSIST / TXO_LANES on a live engine) it is told to read them again
+        env = self._txo_env()
+        if env != self._env_seen and self.handle:
+            self.query(4)                             # TXO_Q_RELOAD_KNOBS
+            self._env_seen = env
 
     # ---- path (every call goes through a torch.ops.texocr operator) -------------------------------------------------
     def encode(self, img: torch.Tensor) -> torch.Tensor:
@@ -189,7 +200,8 @@ class HipEngine:
 
     def query(self, what: int) -> int:
         """txo_engine_query: 0 = the last generate() ran as one persistent launch, 1 = persistent launches that fell back,
-        2 = row ranges (streams) of the last launch-path decode, 3 = the last decode's cross attention ran in latent form."""
+        2 = row ranges (streams) of the last launch-path decode, 3 = the last decode's cross attention ran in latent form,
+        4 = (not a question) re-read the TXO_* development knobs of generate() from the environment."""
         out = C.c_int64(0)
         _lib.check(self.lib.txo_engine_query(self.handle, int(what), C.byref(out)))
         return out.value
