@@ -198,6 +198,12 @@ struct Engine : EngineBase {
     }
     int lat_mode = getenv("TXO_LATENT") ? atoi(getenv("TXO_LATENT")) : -1;
     int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
+    // bf16, width 256: the latent tile on FOUR waves (r05; TXO_LAT_NW=8 brings the 8-wave tile back).  Same one tile per CU, half the waves to
+    // merge and twice the keys per wave: the whole-batch launch at 256 rows 19.3 -> 17.9 us (rocprofv3), generate +2-3 % at 130-192 rows,
+    // beam search 5 x 128 +5 %.  (Two such tiles per CU, 512 tiles of 4 heads at 256 rows, were slower: 22.2 us -- every row's encoder
+    // rows cross the CU's L2 port twice.)  The wave count changes the order in which a row's key tiles are merged: low bits differ from the
+    // 8-wave tile's, within the same bound against the reference.
+    bool lat_nw4 = sizeof(T) == 2 && (getenv("TXO_LAT_NW") ? atoi(getenv("TXO_LAT_NW")) == 4 : true);
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     int enc_walk = getenv("TXO_ENC_WALK") ? atoi(getenv("TXO_ENC_WALK")) : 1;   // encoder kernels walk the rows alternately up and down (encode()); 0 = all upwards
@@ -592,6 +598,7 @@ struct Engine : EngineBase {
             if (exists) {
                 if constexpr (la_supported<T, 64>()) { if (D == 64) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 64>), la_lds_bytes<T, 64>()); }
                 if constexpr (la_supported<T, 256>()) { if (D == 256) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 256>), la_lds_bytes<T, 256>()); }
+                if constexpr (la_supported<T, 256>() && sizeof(T) == 2) { if (D == 256) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 256, 4>), la_lds_bytes<T, 256, 4>()); }
                 if constexpr (la_supported<T, 768>()) { if (D == 768) opt_in(reinterpret_cast<const void*>(&lat_core_kernel<T, 768>), la_lds_bytes<T, 768>()); }
             }
             latent_ok = exists;
@@ -1043,7 +1050,14 @@ struct Engine : EngineBase {
                 else hipLaunchKernelGGL(kern, dim3(nblk), dim3(la_waves<D_>() * 64), lds, s, a);                            \
             }                                                                                                                \
         } while (0)
-        if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
+        if (D == 256 && lat_nw4) {                                // two 4-wave tiles per CU (lat_attn.h: NW_)
+            if constexpr (la_supported<T, 256>() && sizeof(T) == 2) {
+                auto kern = lat_core_kernel<T, 256, 4>;
+                const size_t lds = la_lds_bytes<T, 256, 4>();
+                if (timed) hipExtLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, e0, e1, 0, a);
+                else hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, s, a);
+            }
+        } else if (D == 64) TXO_LA(64); else if (D == 256) TXO_LA(256); else TXO_LA(768);
 #undef TXO_LA
         if (timed) ev_cross.push_back({e0, e1});
     }

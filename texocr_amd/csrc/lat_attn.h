@@ -60,9 +60,12 @@ template <typename T> struct LatCoreArgs {
 };
 
 template <int D_> constexpr int la_waves() { return D_ <= 256 ? 8 : 4; }
-template <typename T, int D_> constexpr size_t la_lds_bytes() {
+// NW_: waves per tile.  The 8-wave tile of the narrow widths leaves ONE tile per CU (72 KB of LDS, 240 registers), so nothing runs under
+// a tile's q' prologue and its cross-wave merge; the 4-wave form (r05: 40 KB) lets two tiles share a CU -- one streams while the other
+// merges -- and doubles the tile slots the head grouping can fill (engine.hip: latent_group).
+template <typename T, int D_, int NW_ = la_waves<D_>()> constexpr size_t la_lds_bytes() {
     // stats | q' image [16][D] | per-wave transposition scratch (later: the waves' partial c)
-    return (size_t)la_waves<D_>() * 16 * 2 * 4 + (size_t)16 * D_ * sizeof(T) + (size_t)la_waves<D_>() * 16 * D_ * sizeof(T);
+    return (size_t)NW_ * 16 * 2 * 4 + (size_t)16 * D_ * sizeof(T) + (size_t)NW_ * 16 * D_ * sizeof(T);
 }
 // fp32 at 768 would need 196 KB of scratch: the K/V form serves that shape
 template <typename T, int D_> constexpr bool la_supported() { return la_lds_bytes<T, D_>() <= 160 * 1024 - 4096; }
@@ -75,9 +78,9 @@ template <int ROWB, int XM> __device__ inline int la_off(int key, int ch) {
     return key * ROWB + (((((ch >> 1) ^ (key & XM)) << 1) | ((ch & 1) ^ ((key >> 2) & 1))) << 4);
 }
 
-template <typename T, int D_>
+template <typename T, int D_, int NW_ = la_waves<D_>()>
 __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile, int tid, unsigned char* lds) {
-    constexpr int NW = la_waves<D_>(), NT = NW * 64;
+    constexpr int NW = NW_, NT = NW * 64;
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
     constexpr int KC = D_ / KCH;                              // 64-byte k-chunks per encoder row
     constexpr int DT = D_ / 16;                               // 16-wide d tiles of c^T
@@ -315,8 +318,8 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
     }
 }
 
-template <typename T, int D_>
-__global__ __launch_bounds__(la_waves<D_>() * 64) void lat_core_kernel(LatCoreArgs<T> a) {
+template <typename T, int D_, int NW_ = la_waves<D_>()>
+__global__ __launch_bounds__(NW_ * 64) void lat_core_kernel(LatCoreArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char la_smem[];
     // workgroups b and b + 8 run on one XCD (round-robin dispatch): every tile that reads ONE image's encoder rows -- its head groups, and in
     // a beam search its kv_div beams -- goes to ONE XCD, whose L2 then fetches those rows once for all of them
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(la_waves<D_>() * 64) void lat_core_kernel(LatCoreAr
     const int tpu = a.kv_div * a.ngrp, unit = (slot / tpu) * 8 + xcd, w = slot - (slot / tpu) * tpu;
     const int row = unit * a.kv_div + w / a.ngrp, hg = w - (w / a.ngrp) * a.ngrp;
     if (row >= a.rows) return;
-    lat_core_tile<T, D_>(a, row * a.ngrp + hg, threadIdx.x, la_smem);
+    lat_core_tile<T, D_, NW_>(a, row * a.ngrp + hg, threadIdx.x, la_smem);
 }
 
 // ---- grouped projection: out[r][g*NG + n] = sum_k A[r][g*KG + k] * W[g*NG + n][k]   (g = head) ---------------------------------
