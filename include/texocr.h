@@ -95,9 +95,9 @@ int txo_decode_prefill(txo_engine* e, const int64_t* tokens_dev, int32_t t, floa
 /* The `mask` argument of decoder.generate / decoder.net (model/decoder.py:95-101,112: a (B, T0) bool over the start tokens, padded
  * with True for every generated token; model/attention.py:130-155: energy filled with -FLT_MAX where query or key is masked).
  * mask_dev: uint8 [B][cols] on the device, 0 = padding; positions >= cols are not padding; NULL clears the mask.  Applies to the
- * txo_decode_step calls of the session opened by txo_decode_begin: a padded position is never attended by a later query.  Rows
- * of padded positions themselves are computed but unspecified (the reference softmaxes them uniformly over all keys; nothing
- * downstream reads them).  txo_decode_prefill refuses to run while a mask is set. */
+ * txo_decode_step and txo_decode_prefill calls of the session opened by txo_decode_begin: a padded position is never attended by a
+ * query that is not padding.  Rows of padded positions themselves are computed but unspecified (the reference softmaxes them
+ * uniformly over all keys; nothing downstream reads them). */
 int txo_decode_set_key_mask(txo_engine* e, const uint8_t* mask_dev, int32_t cols, void* stream);
 
 /* OCRModel.generate (ocr_model.py:46-66) + AutoRegressiveDecoder.generate (decoder.py:77-122), greedy:

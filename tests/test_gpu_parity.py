@@ -1590,11 +1590,25 @@ def test_ragged_start_prefix_with_padding_mask_matches_reference():
     mask = torch.from_numpy(g["mask"]).cuda()
     toks = m.decoder.generate(start, None, meta["max_len"], enc=enc, mask=mask)
     assert np.array_equal(toks.cpu().numpy(), g["tokens"])
-    net = m.decoder.net(start, mask=mask, enc=enc).cpu()
+    net = m.decoder.net(start, mask=mask, enc=enc).cpu()              # ONE masked multi-position pass (r05: csrc/prefill.h, KMASK)
     ref = torch.from_numpy(g["net_logits"])
     keep = torch.from_numpy(g["mask"])
     assert float((net - ref)[keep].abs().max()) < 1e-3
     assert bool(torch.isfinite(net).all())
+    import os
+    os.environ["TXO_NET_STEPWISE"] = "1"                               # the same call as single-position steps
+    try:
+        net_steps = m.decoder.net(start, mask=mask, enc=enc).cpu()
+    finally:
+        os.environ.pop("TXO_NET_STEPWISE")
+    assert float((net_steps - ref)[keep].abs().max()) < 1e-3
+    assert float((net_steps - net)[keep].abs().max()) < 2e-5
+    # perf mode: the masked pass within bf16 noise of the reference at the positions that are not padding, finite everywhere
+    _, _, mb = build(meta, dtype="bf16", max_batch=3)
+    netb = mb.decoder.net(start, mask=mask, enc=mb.encoder(img)).cpu()
+    errb = float((netb - ref)[keep].abs().max())
+    print(f"masked one-pass decoder.net in bf16 vs the reference at non-padded positions: max |dlogit| {errb:.4f}")
+    assert errb < 0.033 and bool(torch.isfinite(netb).all())          # 1.5x the measurement (0.0214)
     plain = m.decoder.generate(start, None, meta["max_len"], enc=enc)
     assert np.array_equal(plain.cpu().numpy(), g["tokens_unmasked"])
     # an all-True mask is the unmasked call; a 1-d start with a 1-d mask works like the reference's squeeze

@@ -1285,7 +1285,6 @@ struct Engine : EngineBase {
     }
 
     int decode_prefill(const int64_t* tokens, int t, float* logits_out, hipStream_t s) override {
-        if (kmask_on) return fail(TXO_E_STATE, "txo_decode_prefill ignores padding masks: clear the key mask or step position by position");
         if (n_lanes != 1) return fail(TXO_E_STATE, "decode_prefill needs a session started by txo_decode_begin");
         if (sImg != sB) return fail(TXO_E_STATE, "decode_prefill is not available inside a beam-search session");
         lanes[0].stream = s;
@@ -1296,9 +1295,11 @@ struct Engine : EngineBase {
     // tokens [B][tok_stride] (the first t of each row); logits_out [B][t][V] or null; last_logits [B][V] or null (final LN + logits of
     // position t-1 only, on the single-position launch).  Runs in the encoder's workspace, image chunks of as many rows as fit.
     template <typename TO>
-    void launch_attn_mq(hipStream_t s, bool causal, const T* q, const T* k, const T* v, TO* out, int nb, int nq, int nk, int kv_rows) {
+    void launch_attn_mq(hipStream_t s, bool causal, const T* q, const T* k, const T* v, TO* out, int nb, int nq, int nk, int kv_rows,
+                        const unsigned char* km = nullptr) {
         const dim3 grid((nq + EA_QBLK - 1) / EA_QBLK, nb * cfg.dec_heads);
-        if (causal) hipLaunchKernelGGL((attn_mq_kernel<T, TO, true>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads);
+        if (causal && km) hipLaunchKernelGGL((attn_mq_kernel<T, TO, true, true>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads, km, Tmax);
+        else if (causal) hipLaunchKernelGGL((attn_mq_kernel<T, TO, true>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads);
         else hipLaunchKernelGGL((attn_mq_kernel<T, TO, false>), grid, dim3(256), 0, s, q, k, v, out, nq, nk, kv_rows, cfg.dec_heads);
     }
     int prefill(const int64_t* tokens, int tok_stride, int t, float* logits_out, float* last_logits, hipStream_t s) {
@@ -1327,7 +1328,7 @@ struct Engine : EngineBase {
                 T* kc = skv + (size_t)(2 * l) * self_stride + (size_t)b0 * heads * Tmax * DH;
                 T* vc = skv + (size_t)(2 * l + 1) * self_stride + (size_t)b0 * heads * Tmax * DH;
                 gemm_plain(s, ez, dec_self[l].wqkv, M, 3 * Id, D, EpiHeadsKV<T>{qbuf, kc, vc, Id, heads, t, Tmax});
-                launch_attn_mq<T>(s, true, qbuf, kc, vc, eao, nb, t, t, Tmax);
+                launch_attn_mq<T>(s, true, qbuf, kc, vc, eao, nb, t, t, Tmax, kmask_on ? kmask + (size_t)b0 * Tmax : nullptr);   // (padding mask of the session, if any)
                 gemm_plain(s, eao, dec_self[l].wo16, M, 2 * D, Id, EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, dec_self[l].bo16});
                 // cross attention over the cached encoder projections (attention.py:114-126: k, v from the raw encoder output)
                 launch_ln<3, T>(s, ey, estats, ez, dec_g, dec_b, M);

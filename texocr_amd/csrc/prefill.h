@@ -68,9 +68,14 @@ template <> __device__ inline u32x4 ld4_f32<bf16>(const bf16* p) {
 //   CAUSAL: key j takes part for query i iff j <= i + (nk - nq)  (attention.py:158-163 with F.pad(mask, (j - i, 0))).
 // Structure of enc_attn_kernel: block = 128 queries, K/V in 64-key f32 LDS stages, S^T = K Q^T so that softmax statistics are
 // per lane and the P accumulators are the B operand of O^T += V^T P^T.
-template <typename TI, typename TO, bool CAUSAL>
+// KMASK: the padding mask of decoder.net / decoder.generate (attention.py:130-155: energy filled with -FLT_MAX where q_mask (x) k_mask is
+//   False).  kmask [images][kmask_stride] bytes, 0 = padding.  A key that is padding is never attended by a query that is not; the row of a
+//   query that IS padding is unspecified here as on the single-position path (the reference softmaxes it uniformly over all keys, future ones
+//   included; nothing reads it): it ignores the mask, so that it stays finite -- its k / v rows land in the cache and are masked at every use.
+template <typename TI, typename TO, bool CAUSAL, bool KMASK = false>
 __global__ __launch_bounds__(256) void attn_mq_kernel(const TI* __restrict__ Q, const TI* __restrict__ Kg, const TI* __restrict__ Vg,
-                                                      TO* __restrict__ out, int nq, int nk, int kv_rows, int heads) {
+                                                      TO* __restrict__ out, int nq, int nk, int kv_rows, int heads,
+                                                      const unsigned char* __restrict__ kmask = nullptr, int kmask_stride = 0) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][EA_KSTAGE * 256];   // [buf][K|V], f32 rows
     const int bh = blockIdx.y, b = bh / heads, head = bh - b * heads;
     const int q0 = blockIdx.x * EA_QBLK;
@@ -98,6 +103,12 @@ __global__ __launch_bounds__(256) void attn_mq_kernel(const TI* __restrict__ Q, 
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
+    [[maybe_unused]] bool q_valid[2] = {true, true};          // KMASK: this lane's query is not padding (query i sits at position i + off)
+    if constexpr (KMASK) {
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+            q_valid[qt] = kmask[(size_t)b * kmask_stride + min(q0 + wave * 32 + qt * 16 + lc, nq - 1) + off] != 0;
+    }
 
     u32x4 rk[4], rv[4];
     auto load_stage = [&](int s) {
@@ -143,8 +154,21 @@ __global__ __launch_bounds__(256) void attn_mq_kernel(const TI* __restrict__ Q, 
             }
         }
         const int kbase = s * EA_KSTAGE;
+        if constexpr (KMASK) {                                // padded keys, for the queries that are not padding themselves
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int k0 = kbase + kt * 16 + lg * 4;      // this lane's four keys of the tile (a multiple of 4: one aligned 4-byte read)
+                const unsigned km = k0 < nk ? *reinterpret_cast<const unsigned*>(kmask + (size_t)b * kmask_stride + k0) : 0xffffffffu;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool pad = ((km >> (8 * r)) & 0xffu) == 0 && k0 + r < nk;
+#pragma unroll
+                    for (int qt = 0; qt < 2; ++qt) if (pad && q_valid[qt]) sc[qt][kt][r] = -1e30f;
+                }
+            }
+        }
         // keys past nk (last stage) and, causal, keys after the query: score -1e30 -> probability exactly 0 once a real key set the maximum
-        // (key 0 is never masked: it is in stage 0 for every query)
+        // (without a mask key 0 is in stage 0 for every query; with one a whole stage may be masked: p = 0 below while the maximum is -1e30)
         if (CAUSAL || kbase + EA_KSTAGE > nk) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {

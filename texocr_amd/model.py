@@ -306,19 +306,24 @@ class Transformer(nn.Module):
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
         eng.decode_begin(enc)
+        one_pass = eng.dims.vocab % 8 == 0 and x.shape[1] <= eng.max_batch * eng.max_tokens and os.environ.get("TXO_NET_STEPWISE") is None
         if padded:
-            # attention.py:130-155: a padded position is never attended by another query.  Logits AT padded positions are unspecified here
-            # (the reference softmaxes such a row uniformly over all keys, future ones included; nothing reads it): single-position steps
+            # attention.py:130-155: a padded position is never attended by a query that is not padding.  Logits AT padded positions are
+            # unspecified here (the reference softmaxes such a row uniformly over all keys, future ones included; nothing reads it)
             eng.set_key_mask(mask.to(x.device))
-            out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
-            xt = x.t().contiguous()
-            for t in range(x.shape[1]):
-                out[:, t] = eng.decode_step(t, xt[t])[0]
-            eng.set_key_mask(None)
-            return out
+            try:
+                if one_pass:
+                    return eng.decode_prefill(x)              # one causal multi-position pass with the key mask (csrc/prefill.h)
+                out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
+                xt = x.t().contiguous()
+                for t in range(x.shape[1]):
+                    out[:, t] = eng.decode_step(t, xt[t])[0]
+                return out
+            finally:
+                eng.set_key_mask(None)
         # the one-pass prefill needs a vocabulary that is a multiple of 8 and a prefix that fits the engine's workspace
         # (max_batch * max_tokens rows); anything else takes the single-position steps
-        if eng.dims.vocab % 8 == 0 and x.shape[1] <= eng.max_batch * eng.max_tokens and os.environ.get("TXO_NET_STEPWISE") is None:
+        if one_pass:
             return eng.decode_prefill(x)
         out = torch.empty((x.shape[0], x.shape[1], eng.dims.vocab), device=x.device, dtype=torch.float32)
         xt = x.t().contiguous()                                   # fallback (odd vocabulary sizes; tests): one cached step per position
@@ -417,7 +422,7 @@ class AutoRegressiveDecoder(nn.Module):
                 if m is not None:
                     eng.set_key_mask(m[:, -L:])
             wt = window.t().contiguous()
-            if m is None and n - 1 - valid > 1 and eng.dims.vocab % 8 == 0 and n - 1 <= eng.max_batch * eng.max_tokens:
+            if n - 1 - valid > 1 and eng.dims.vocab % 8 == 0 and n - 1 <= eng.max_batch * eng.max_tokens:   # (with or without a padding mask)
                 eng.decode_prefill(window[:, :n - 1].contiguous(), want_logits=False)   # positions 0..n-2 in one pass
             else:
                 for p in range(valid, n - 1):
