@@ -11,7 +11,8 @@ Objects on the line besides the contract's fields:
   roofline     -- decode-step cross-attention kernel (the HBM-bound kernel north_star names): algorithmic
                   bytes per launch = B*heads*2*N*64*sizeof(dtype), divided by the kernel's average launch
                   duration measured with HIP events bound to the dispatches of the LAST timed step.
-                  `traffic` = PMC bytes per launch from a separate rocprofv3 pass (file named in `traffic_source`).
+                  `traffic` = HBM bytes per launch from the PMC counters, measured in this run by rocprofv3 --pmc child passes of this
+                  script (live_pmc; N=1 default run) or, failing that, from the tracked profiles/ file -- `traffic_source` says which.
   cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") on this host: `value` = recompute mode = the reference's
                   algorithm (no KV cache, decoder.py:97-103) on a bounded sample; `cached` = the same oracle with a KV cache.
   fp32_parity_mode, sampled_decode, b256, cfg4, cfg5_beam (N=1 only, after the timed region; --no-extras skips them):
@@ -49,10 +50,61 @@ def parse():
                     help="also run the WHOLE un-sampled reference-algorithm generate on the CPU (minutes): validates the sampled estimate")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / batch-256 / config-4 side measurements")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect the HBM counters of the dominant launches in this run (rocprofv3 --pmc child passes, N=1 only); "
+                         "`traffic` then comes from the tracked profiles/ file and says so")
     ap.add_argument("--model", default="default", choices=["default", "cfg4"],
                     help="cfg4 = BASELINE configs[3] (ViT-Base 12L/768d encoder + 6L/768d decoder) as the main workload: for profiling "
                          "runs; the headline metric is quoted on the default model")
     return ap.parse_args()
+
+
+LIVE_PMC = {}          # kind -> HBM bytes per launch measured in THIS run (live_pmc), read where the roofline objects are built
+
+
+def live_pmc(a):
+    """HBM bytes per launch of the dominant kernels from the PMC counters, collected in THIS run the way MI355X_MICROARCH.md's HBM section
+    prescribes: one counter per rocprofv3 pass (FETCH_SIZE, WRITE_SIZE), --kernel-trace only, read bytes = 2 * FETCH_SIZE (gfx950 counts
+    16-byte-per-lane streams at half) + WRITE_SIZE.  Each pass is a CHILD run of this script (one generate, no side measurements) started
+    BEFORE this process touches the GPU.  Kinds: 'persist' = the persistent decode launch of the headline workload (all max_len
+    positions); 'b256' = the whole-batch cross-attention launch at batch 256 (one row range, 24 positions: bytes per launch do not
+    depend on the position).  Anything that goes wrong leaves the kind out: the line then quotes the tracked profiles/ file and says so."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return
+    tmp = tempfile.mkdtemp(prefix="txo_pmc_", dir="/tmp")
+    base = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--settle-seconds", "0", "--dtype", a.dtype,
+            "--height", str(a.height), "--width", str(a.width), "--no-cpu-baseline", "--no-roofline", "--no-extras", "--no-live-pmc"]
+    kinds = [("persist", {"TXO_PERSIST": "1"}, ["--batch", str(a.batch), "--max-len", str(a.max_len)], "decode_persist_kernel")]
+    if not a.no_extras and a.dtype == "bf16":
+        kinds.append(("b256", {"TXO_PERSIST": "0", "TXO_LANES": "1"}, ["--batch", "256", "--max-len", "24"], "lat_core_kernel"))
+    t_start = time.perf_counter()
+    try:
+        for kind, env_extra, args, kname in kinds:
+            vals = {}
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                if time.perf_counter() - t_start > 240:                 # bounded: the default run has to finish within minutes
+                    raise TimeoutError
+                d = os.path.join(tmp, kind, counter)
+                env = dict(os.environ, TMPDIR="/tmp", **env_extra)
+                subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + base + args,
+                               env=env, cwd=ROOT, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                got = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        if r.get("Counter_Name") == counter and kname in r.get("Kernel_Name", ""):
+                            got.append(float(r["Counter_Value"]))
+                if not got:
+                    raise RuntimeError(f"no {counter} rows for {kname}")
+                vals[counter] = sum(got) / len(got)                     # KB per launch
+            LIVE_PMC[kind] = {"traffic_bytes": int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
+                              "source": "measured in this run: two rocprofv3 --pmc child passes of this script (FETCH_SIZE, WRITE_SIZE; "
+                                        "--kernel-trace only), read bytes = 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, average over the pass's launches"}
+    except Exception:
+        pass
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _cpu_model():
@@ -284,6 +336,9 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
                 out["roofline"]["traffic_source"] = fn + " (separate rocprofv3 --pmc passes; not measured in this run)"
         except Exception:
             pass
+        if B == 256 and latent and dims.embed_dim == 256 and dtype == "bf16" and "b256" in LIVE_PMC:
+            out["roofline"]["traffic"] = LIVE_PMC["b256"]["traffic_bytes"]
+            out["roofline"]["traffic_source"] = LIVE_PMC["b256"]["source"]
     if want_encoder:
         eng.profile(True)
         m.generate(img, a.max_len)
@@ -301,6 +356,8 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
 
 def main():
     a = parse()
+    if (not a.no_live_pmc and not a.no_roofline and a.model == "default" and "RANK" not in os.environ and a.gpus == 1):
+        live_pmc(a)                                       # child processes: before this process initialises the GPU
     import torch
     import torch.distributed as dist
     from texocr_amd.config import Dims
@@ -414,6 +471,8 @@ def main():
                 algo = a.batch * heads * 64 * esz * Ld * rows
                 ach = algo / (ms_live * 1e-3) / 1e9 if ms_live > 0 else 0.0
                 traffic, tsrc = pmc("persist_")
+                if "persist" in LIVE_PMC:
+                    traffic, tsrc = LIVE_PMC["persist"]["traffic_bytes"], LIVE_PMC["persist"]["source"]
                 result["roofline"] = {
                     "kernel": "decode_persist_kernel (the whole 256-position decode loop as one launch; texocr_amd/csrc/persist.h)",
                     "bound": "hbm", "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
