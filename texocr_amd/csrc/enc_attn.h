@@ -17,6 +17,7 @@
 // rate; everything else (8 exps, 32 rescale FMAs, 20 LDS reads per 16 keys) hides behind it.
 // Bound: MFMA f32 (157 TF peak).
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace txo {
@@ -490,19 +491,33 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
     const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
 
     const int nstage = (N + EA_KSTAGE - 1) / EA_KSTAGE;
+    // r05: the ragged ends.  N = 589 is 9 key stages of 64 + one of 13, and 4 query blocks of 128 + one of 77: the last stage runs only the
+    // 16-key tiles / 32-key k-steps that hold a key (one of four / one of two), and a wave whose 32 queries all lie beyond N only stages
+    // K / V and keeps the barriers.  Same arithmetic for every key and query that exists (a skipped tile contributed exact zeros).
+    const bool active = __builtin_amdgcn_readfirstlane(q0 + wave * 32) < N;
     load_stage(0);
     store_stage(0);
     __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
+    auto stage = [&](int s, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;        // LAST: the stage may be ragged (fewer than 64 keys)
         const int buf = s & 1;
         if (s + 1 < nstage) load_stage(s + 1);
+        if (active) {
         const unsigned char* Ks = lds[buf][0];
         const unsigned char* Vs = lds[buf][1];
+        const int kbase = s * EA_KSTAGE;
+        const int nkt = LAST ? min(4, (N - kbase + 15) >> 4) : 4;      // 16-key tiles of this stage that hold a key (block-uniform)
 
         // ---- S^T - m for 64 keys x 32 queries: 16 MFMA, the running maximum as the initial accumulator ----
         f32x4 sc[2][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
+            if (LAST && kt >= nkt) {
+                asm volatile("; key tile past the last key" ::: "memory");   // a real (scalar) branch around the tile's MFMAs
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) sc[qt][kt] = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
+                continue;
+            }
             u32x4 kf[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) kf[ks] = ld16(Ks + swz128(kt * 16 + lc, ks * 4 + lg));
@@ -515,8 +530,7 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
                 sc[qt][kt] = a;
             }
         }
-        const int kbase = s * EA_KSTAGE;
-        if (kbase + EA_KSTAGE > N) {
+        if (LAST && kbase + EA_KSTAGE > N) {
             asm volatile("; ragged last stage" ::: "memory");    // keep this a branch: if-converted it costs ~60 VALU ops in EVERY stage
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -559,6 +573,7 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
             unsigned pk[8];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
+                if (LAST && kt >= nkt) { pk[2 * kt] = 0u; pk[2 * kt + 1] = 0u; continue; }     // (2^-1e30 = 0: the same zeros, not computed)
                 float p[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[qt][kt][r]);
@@ -570,6 +585,10 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
         // ---- O^T += V^T P^T (16 MFMA) and the normaliser tile (4 MFMA) ----
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
+            if (LAST && k2 * 2 >= nkt) {
+                asm volatile("; k-step past the last key" ::: "memory");
+                continue;                                      // its P operand is all zeros
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const unsigned char* va = Vs + k2 * (32 * 128) + vbase + vcol[dt];
@@ -583,9 +602,13 @@ __global__ __launch_bounds__(256) void enc_attn_bf16_v2_kernel(const bf16* __res
             mma16<bf16>(o[0][4], ones, pb[0][k2]);
             mma16<bf16>(o[1][4], ones, pb[1][k2]);
         }
+        }
         if (s + 1 < nstage) store_stage(buf ^ 1);
         __syncthreads();
-    }
+    };
+    for (int s = 0; s + 1 < nstage; ++s) stage(s, std::false_type{});
+    stage(nstage - 1, std::true_type{});
+    if (!active) return;                                       // (behind the last barrier)
 
     // ---- normalise, transpose through LDS (wave-private 32 x 64 f32 tile), store whole rows ----
     float* tile = reinterpret_cast<float*>(&lds[0][0][0]) + wave * (32 * 64);
