@@ -1,7 +1,7 @@
 """Decode A/B of engines BUILT under different environments (knobs the engine reads once, at creation), interleaved in one process:
    python probes/dec_ab.py <what> <B> "-" "TXO_LAT_NW=4" ...      what = greedy | sample | beam5   (bf16, 224x672, 256 positions)
 Prints min / median ms per generate and whether the tokens equal the first configuration's."""
-import os, sys, time, statistics
+import os, sys, time, statistics, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from texocr_amd.config import Dims
@@ -34,4 +34,4 @@ for rnd in range(3):
         torch.cuda.synchronize(); res[c].append((time.perf_counter() - t0) / 3); outs[c] = out
 for c in cfgs:
     eq = float((outs[c] == outs[cfgs[0]]).float().mean())
-    print(f"{what} B={B} [{c:28s}] min {min(res[c])*1e3:8.2f} ms  median {statistics.median(res[c])*1e3:8.2f} ms  = {B/min(res[c]):7.1f} img/s   tokens equal to the first: {eq:.4f}", flush=True)
+    print(f"{what} B={B} [{c:28s}] min {min(res[c])*1e3:8.2f} ms  median {statistics.median(res[c])*1e3:8.2f} ms  = {B/min(res[c]):7.1f} img/s   tokens equal to the first: {eq:.4f}  sha1 {hashlib.sha1(outs[c].cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)
