@@ -13,14 +13,14 @@ H, W, T = 224, 672, 256
 d = Dims(canvas=672)
 sd = synth.synth_state_dict(d, 0)
 rows = B * 5 if what == "beam5" else B
-ms = {}
+ms = {}; envs = {}
 for c in cfgs:
     kv = dict(x.split("=", 1) for x in c.split(",") if "=" in x)
     os.environ.update(kv)
     m = model_from_dims(d, dtype="bf16", max_batch=rows, max_tokens=d.n_tokens(H, W))
     for k in kv: os.environ.pop(k)
     m.load_state_dict(sd); m.eos_token = None
-    ms[c] = m
+    ms[c] = m; envs[c] = kv
 img = torch.rand((B, 3, H, W), device="cuda")
 def run(m):
     if what == "greedy": return m.generate(img, T)
@@ -29,9 +29,11 @@ def run(m):
 res = {c: [] for c in cfgs}; outs = {}
 for rnd in range(3):
     for c, m in ms.items():
+        os.environ.update(envs[c])          # (the per-call knobs are re-read when the TXO_* environment changes: texocr_amd/model.py)
         run(m); torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(3): out = run(m)
         torch.cuda.synchronize(); res[c].append((time.perf_counter() - t0) / 3); outs[c] = out
+        for k in envs[c]: os.environ.pop(k)
 for c in cfgs:
     eq = float((outs[c] == outs[cfgs[0]]).float().mean())
     print(f"{what} B={B} [{c:28s}] min {min(res[c])*1e3:8.2f} ms  median {statistics.median(res[c])*1e3:8.2f} ms  = {B/min(res[c]):7.1f} img/s   tokens equal to the first: {eq:.4f}  sha1 {hashlib.sha1(outs[c].cpu().numpy().tobytes()).hexdigest()[:12]}", flush=True)
