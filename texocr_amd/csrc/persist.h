@@ -4,7 +4,7 @@
 // stages is an in-launch hand-off instead of a kernel boundary.
 //
 // Why: at batch 64 a step is a chain of 30 dependent launches whose ~3.5 us each (boundary + launch ramp + cold operand
-// fetch) is 105 of its 173 us, while its HBM traffic needs ~58 us.  Inside one launch a stage
+// fetch) is 105 of its 173 us, while its HBM traffic needs ~58 us (DESIGN_HISTORY.md section 5).  Inside one launch a stage
 //   * requests its weights BEFORE it waits for the previous stage (they do not depend on the chain), and
 //   * hands its rows over through the L2 it shares with its consumers (probes/team_seam.hip: 1.5 us per stage against
 //     3.1 us for an empty dependent launch).
