@@ -1232,6 +1232,16 @@ struct Engine : EngineBase {
                     stamp_names[k2].c_str(), nb, (first - t0) / 100.0, (last_in - t0) / 100.0, (mid_lo - t0) / 100.0, (mid_hi - t0) / 100.0,
                     (first_out - t0) / 100.0, (last - t0) / 100.0);
         }
+        // TXO_STAMPS_RAW=<substring>: also one line per block of the launches whose name contains it (which CU / tile is the slow one)
+        if (const char* raw = getenv("TXO_STAMPS_RAW")) {
+            for (int k2 = 0; k2 < nk; ++k2) {
+                if (stamp_names[k2].find(raw) == std::string::npos) continue;
+                for (int b = 0; b < STAMP_BLOCKS; ++b) {
+                    const unsigned long long* d = &h[((size_t)k2 * STAMP_BLOCKS + b) * 3];
+                    if (d[0]) fprintf(f, "raw %d %-24s block %4d  %7.2f %7.2f %7.2f\n", k2, stamp_names[k2].c_str(), b, (d[0] - t0) / 100.0, (d[1] - t0) / 100.0, (d[2] - t0) / 100.0);
+                }
+            }
+        }
         fclose(f);
     }
 
