@@ -21,6 +21,7 @@ for c in cfgs:
     for k in kv: os.environ.pop(k)
     m.load_state_dict(sd); m.eos_token = None
     ms[c] = m; envs[c] = kv
+torch.manual_seed(0)
 img = torch.rand((B, 3, H, W), device="cuda")
 def run(m):
     if what == "greedy": return m.generate(img, T)

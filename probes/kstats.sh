@@ -5,7 +5,7 @@ set -e
 OUT=${TXO_KSTATS_ASM:-/tmp/txo_engine_gfx950.s}
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 if [ ! -f "$OUT" ] || [ -n "$(find "$HERE/texocr_amd/csrc" -newer "$OUT" -name '*.h*' | head -1)" ]; then
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -mllvm -amdgpu-mfma-vgpr-form -ffp-contract=on \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only -S -mllvm -amdgpu-mfma-vgpr-form -ffp-contract=on -fno-honor-nans \
       ${TXO_EXTRA_FLAGS} "$HERE/texocr_amd/csrc/engine.hip" -o "$OUT" 2>/dev/null
 fi
 python3 - "$OUT" "${1:-.}" <<'PY'
