@@ -1203,7 +1203,7 @@ struct Engine : EngineBase {
             BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok + r0, bscore + r0, bfin + r0, bm->path_cur + r0 * Tmax, bm->path_nxt + r0 * Tmax, Tmax,
                         bparent + r0, btok + r0, Bmax, st + li, done_flag + (size_t)li * Tmax, eos, (int)r0};
             hipLaunchKernelGGL(beam_select_kernel, dim3(nb / bm->k), dim3(256), 0, s, ba);
-        } else if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(nb), dim3(64), (size_t)V * sizeof(float), s, sa);
+        } else if (sample_mode) launch_sample_step(s, nb, sa);
         else hipLaunchKernelGGL(argmax_step_kernel, dim3(nb), dim3(64), 0, s, sa);
         dbg(s, "argmax");
         if (prof) { (void)hipEventRecord(e1, s); ev_step.push_back({e0, e1}); }
@@ -1668,7 +1668,7 @@ struct Engine : EngineBase {
             if (int r = prefill(tokens_out + (i - Tmax), max_len, Tmax, nullptr, dlogits, s)) return r;
             hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, i);
             StepArgs sa{dlogits, V, B, cur_tok, tokens_out, max_len, logits_out, st, eos_seen, flag - i, eos, sample_topk, 1.0f / sample_temp, sample_seed, 0};
-            if (sample_mode) hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(64), (size_t)V * sizeof(float), s, sa);
+            if (sample_mode) launch_sample_step(s, B, sa);
             else hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(64), 0, s, sa);
             *steps = i + 1;
             if (eos >= 0) {                                       // slow path: one host look per token

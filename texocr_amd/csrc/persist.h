@@ -495,8 +495,8 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                     // the same function and key as the launch path's sample_step_kernel, hence the same draw.  The row lives in
                     // registers (step.h: vocabularies up to 1024 entries; Engine::persist_usable sends larger ones to the launch path).
                     auto ld = [&](int j) { return ldc_f32<true>(lg + j); };
-                    if constexpr (sizeof(T) == 2) bi = sample_row_regs(ld, lo, a.V, lane, a.sample_topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
-                    else bi = sample_row_regs_call(ld, lo, a.V, lane, a.sample_topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
+                    auto ld4 = [&](int j) { return ldc16_at<true>(a.dlogits, (size_t)row * a.V + j); };
+                    bi = sample_row_regs(ld, ld4, lo, a.V, lane, a.sample_topk, a.inv_temp, a.seed, (unsigned)row, (unsigned)t);
                 } else {
                 if ((a.V & 3) == 0) {                          // four 16-byte pieces per lane in flight
                     const int n4 = a.V >> 2;

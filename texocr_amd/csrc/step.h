@@ -181,24 +181,52 @@ __device__ inline int sample_row_lds(Load&& load, float* row_lds, float* lo, int
 #define TXO_SAMPLER_LDS 0      // 1: build the LDS form only (tests of its equality with the register form: probes/ab_libs.sh)
 #endif
 constexpr int SR_PER = 16;
-template <class Load>
-__device__ __forceinline__ int sample_row_regs(Load&& load, float* lo, int V, int lane, int topk, float inv_temp,
+// load4(j): four consecutive logits from index j (a multiple of 4) as one 16-byte request (their bits as u32x4); used when V % 4 == 0.
+// r05: the row arrives in 16-byte requests, the probabilities are computed ONCE, without a branch per slot, and kept in the key
+// registers for the owner's walk (the walk used to recompute them behind 16 more exec-mask branches): sample_step_kernel 13.0 -> 9.7 us
+// per launch (rocprofv3, batch 64), the sampling stage of the persistent launch 10.7 -> 7.4 us by its stamps -- and the generate of the
+// persistent launch unchanged (35.1 ms at batch 64 before and after: profiles/r05_sampler.txt).  Kept set, probabilities, summation
+// order and RNG key are unchanged: the same draws (token hashes equal).
+template <class Load, class Load4>
+__device__ __forceinline__ int sample_row_regs(Load&& load, Load4&& load4, float* lo, int V, int lane, int topk, float inv_temp,
                                                unsigned long long seed, unsigned row, unsigned t) {
     // (inlined on purpose: as a called function it put the persistent decode kernel under the calling convention -- values live
     // across the call site pinned to callee-saved registers -- and cost the GREEDY decode 1.5 %; ONE 16-register array keeps it
     // inside that kernel's budget)
+    // (the lane index made opaque: inside the persistent kernel's position loop everything below that depends only on the lane and V -- 16 slot
+    // masks in SGPR pairs -- is otherwise hoisted out of the loop and held across all of its stages)
+    asm volatile("" : "+v"(lane));
     const int per = (V + 63) / 64, j0 = lane * per;           // the LDS form's lane-contiguous chunks [j0, j1)
-    // ONE register array: the order-preserving keys (a logit is recovered from its key by unfkey)
+    // ONE register array: the order-preserving keys (a logit is recovered from its key by unfkey), later the probabilities
     auto unfkey = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); };
     unsigned key[SR_PER];
     float mx = -3.4e38f;
+    // (no branch on a lane's own condition anywhere below: requests are clamped, results masked -- hipcc otherwise wraps every slot in an
+    // exec-mask branch and copies the whole key array at each of them)
+    const int nin = max(0, min(per, V - j0));                 // this lane's real slots
+    if ((V & 3) == 0 && (per & 3) == 0) {                     // (wave-uniform) whole 16-byte pieces: j0 and V are multiples of 4
 #pragma unroll
-    for (int u = 0; u < SR_PER; ++u) {
-        const int j = j0 + u;
-        const bool in = u < per && j < V;
-        const float v = in ? load(min(j, V - 1)) : 0.f;
-        if (in) { if (lo) lo[j] = v; mx = fmaxf(mx, v); }
-        key[u] = in ? fkey(v) : 0u;                           // 0 lies below every real key
+        for (int c = 0; c < SR_PER / 4; ++c) {
+            const bool in = 4 * c < nin;
+            const u32x4 w = load4(in ? j0 + 4 * c : 0);
+            const float vx = __uint_as_float(w.x), vy = __uint_as_float(w.y), vz = __uint_as_float(w.z), vw = __uint_as_float(w.w);
+            const unsigned m = in ? 0xffffffffu : 0u;         // 0 lies below every real key
+            key[4 * c + 0] = fkey(vx) & m; key[4 * c + 1] = fkey(vy) & m; key[4 * c + 2] = fkey(vz) & m; key[4 * c + 3] = fkey(vw) & m;
+            mx = fmaxf(mx, in ? fmaxf(fmaxf(vx, vy), fmaxf(vz, vw)) : -3.4e38f);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) {
+            const bool in = u < nin;
+            const float v = load(in ? j0 + u : 0);
+            key[u] = fkey(v) & (in ? 0xffffffffu : 0u);
+            mx = fmaxf(mx, in ? v : -3.4e38f);
+        }
+    }
+    if (lo) {                                                 // (wave-uniform) the caller wants the logits of this position
+        float* dst = lo + j0;
+#pragma unroll
+        for (int u = 0; u < SR_PER; ++u) { if (u < nin) dst[u] = unfkey(key[u]); }
     }
     mx = wave_max(mx);
     const int k = min(max(topk, 1), V);
@@ -211,26 +239,31 @@ __device__ __forceinline__ int sample_row_regs(Load&& load, float* lo, int V, in
         if (cnt >= k) prefix = cand;
         if (cnt == k) break;                                  // exactly k entries at or above cand: the kept set is fixed
     }
+    // slots beyond the row hold key 0: never above a prefix, and equal to it only when prefix == 0
     int ngt = 0, neq = 0;
 #pragma unroll
-    for (int u = 0; u < SR_PER; ++u) { ngt += key[u] > prefix; neq += (key[u] == prefix) && (u < per && j0 + u < V); }
+    for (int u = 0; u < SR_PER; ++u) { ngt += key[u] > prefix; neq += (key[u] == prefix) && u < nin; }
     int ngt_all = wave_sum(ngt), eq_before = neq;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(eq_before, o, 64); if (lane >= o) eq_before += v; }
     eq_before -= neq;
     const int eq_mine = (k - ngt_all) - eq_before;            // ties this lane may keep, in index order
-    // probability of slot u (0 when not kept); `ties` = ties of this lane already passed
-    auto prob = [&](int u, int& ties) -> float {
-        const bool in = u < per && j0 + u < V;
-        bool keep = in && key[u] > prefix;
-        if (in && key[u] == prefix) { if (ties < eq_mine) keep = true; ++ties; }
-        return keep ? expf((unfkey(key[u]) - mx) * inv_temp) : 0.f;
-    };
+    // probabilities (0 when not kept), computed for every slot and selected: no branch around the exponential
     float psum = 0.f;
     {
         int ties = 0;
 #pragma unroll
-        for (int u = 0; u < SR_PER; ++u) { const float pu = prob(u, ties); if (u < per && j0 + u < V) psum += pu; }
+        for (int u = 0; u < SR_PER; ++u) {
+            const bool in = u < nin;
+            const unsigned ku = key[u];
+            const bool eq = in && ku == prefix;
+            const bool keep = in && (ku > prefix || (eq && ties < eq_mine));
+            ties += eq ? 1 : 0;
+            const float e = expf(((in ? unfkey(ku) : mx) - mx) * inv_temp);
+            const float pu = keep ? e : 0.f;
+            key[u] = __float_as_uint(pu);
+            psum += pu;                                       // (+ 0 for a slot that is not kept or not there: the same bits as skipping it)
+        }
     }
     float incl = psum;
 #pragma unroll
@@ -242,51 +275,49 @@ __device__ __forceinline__ int sample_row_regs(Load&& load, float* lo, int V, in
     const float target = uu * total;
     const unsigned long long hit = __ballot(incl >= target && psum > 0.f);
     const int owner = hit ? (int)__builtin_ctzll(hit) : 63;
+    // every lane walks its own chunk (no branch); the owner's result is the draw
     int pick = -1;
-    if (lane == owner) {                              // the owner walks its chunk again (probabilities recomputed, not stored)
+    {
         float run = incl - psum;
         bool done = false;
-        int ties = 0;
 #pragma unroll
         for (int u = 0; u < SR_PER; ++u) {
-            const float pu = prob(u, ties);
-            if (!done && pu > 0.f) { pick = j0 + u; run += pu; if (run >= target) done = true; }
+            const float pu = __uint_as_float(key[u]);
+            const bool take = !done && pu > 0.f;
+            pick = take ? j0 + u : pick;
+            run = take ? run + pu : run;
+            done = done || (take && run >= target);
         }
     }
     pick = __shfl(pick, owner, 64);
-    if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max
+    if (pick < 0) {                                   // numerical corner (target beyond the last kept entry): take the arg max (the row is read again)
         float best = -3.4e38f; int bi = 0x7fffffff;
-#pragma unroll
-        for (int u = 0; u < SR_PER; ++u) if (u < per && j0 + u < V && unfkey(key[u]) > best) { best = unfkey(key[u]); bi = j0 + u; }
+        for (int u = 0; u < nin; ++u) { const float v = load(j0 + u); if (v > best) { best = v; bi = j0 + u; } }
         wave_argmax(best, bi);
         pick = bi;
     }
     return pick;
 }
 
-// the same as a CALLED function: for a kernel that has no 16 registers to spare (the fp32 persistent decode kernel, which the
-// inlined form pushes into scratch)
-template <class Load>
-__device__ __attribute__((noinline)) int sample_row_regs_call(Load&& load, float* lo, int V, int lane, int topk, float inv_temp,
-                                                              unsigned long long seed, unsigned row, unsigned t) {
-    return sample_row_regs(load, lo, V, lane, topk, inv_temp, seed, row, t);
-}
-
-template <class Load>
-__device__ inline int sample_row(Load&& load, float* row_lds, float* lo, int V, int lane, int topk, float inv_temp,
-                                 unsigned long long seed, unsigned row, unsigned t) {
-    if (V <= 64 * SR_PER && !TXO_SAMPLER_LDS) return sample_row_regs(load, lo, V, lane, topk, inv_temp, seed, row, t);
-    return sample_row_lds(load, row_lds, lo, V, lane, topk, inv_temp, seed, row, t);
-}
-
+// REGS: the row in registers (host: vocabularies up to 64 * SR_PER entries) or staged in LDS.  Two kernels, not one with a branch: with both
+// forms in one body hipcc keeps a 36-byte stack object (private segment enabled for every launch) that neither form has alone.
+__host__ __device__ inline bool sample_in_regs(int V) { return V <= 64 * SR_PER && !TXO_SAMPLER_LDS; }
+template <bool REGS>
 __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     extern __shared__ float row_lds[];
     const int row = blockIdx.x, lane = threadIdx.x, V = a.V;
     const int t = a.st->t;
     const float* lg = a.logits + (size_t)row * V;
     float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
-    const int pick = sample_row([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)(a.row0 + row), (unsigned)t);
+    int pick;
+    if constexpr (REGS) pick = sample_row_regs([&](int j) { return lg[j]; }, [&](int j) { return ld16(lg + j); }, lo, V, lane, a.topk, a.inv_temp, a.seed,
+                                               (unsigned)(a.row0 + row), (unsigned)t);
+    else pick = sample_row_lds([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)(a.row0 + row), (unsigned)t);
     if (lane == 0) commit_token(a, row, t, pick);
+}
+inline void launch_sample_step(hipStream_t s, int rows, const StepArgs& sa) {
+    if (sample_in_regs(sa.V)) hipLaunchKernelGGL(sample_step_kernel<true>, dim3(rows), dim3(64), 0, s, sa);
+    else hipLaunchKernelGGL(sample_step_kernel<false>, dim3(rows), dim3(64), (size_t)sa.V * sizeof(float), s, sa);
 }
 
 // ---- beam search (a build extension: the reference has no beam search) -----------------------------------
