@@ -1019,6 +1019,33 @@ def test_persistent_decode_samples_like_the_launch_path(dtype, B):
         assert torch.equal(a, b) and a.shape[1] <= 40
 
 
+@pytest.mark.parametrize("vocab", [999, 950, 512, 1100])
+def test_sampler_row_request_forms_and_the_oracle_top_k(vocab):
+    """The register-form sampler requests a row in 16-byte pieces when the vocabulary and a lane's chunk are multiples of 4 (1000, 512), one
+    logit at a time otherwise (999: V % 4, 950: 15 slots per lane), and the LDS form serves vocabularies beyond 1024 (1100).  On every
+    form: persistent launch and launch path draw the same tokens from the same logits, the draws are inside the reference's top-k support
+    (utils.py:85-91: k = int(0.1 V) largest), and they are draws (not all arg-maxes)."""
+    import dataclasses
+    d = dataclasses.replace(Dims(canvas=224), vocab=vocab, bos=vocab - 2, eos=vocab - 3, pad=vocab - 1)
+    d, sd, m = build(d, seed=3, dtype="fp32", max_batch=21)
+    m.eos_token = None
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.rand((21, 3, 64, 224), generator=g, device="cuda")
+    kw = dict(temp=0.7, decode="sample", seed=4, return_logits=True)
+    if vocab <= 1024:
+        (tp, lp), (tl, ll) = _both_paths(m, img, 24, **kw)
+        assert torch.equal(tp, tl) and torch.equal(lp, ll)
+    else:                                                    # (the persistent launch's sampler keeps the row in registers: launches serve this one)
+        tp, lp = m.generate(img, 24, **kw)
+        assert m._engine.query(0) == 0
+        t2, l2 = m.generate(img, 24, **kw)
+        assert torch.equal(tp, t2) and torch.equal(lp, l2)
+    k = max(int((1 - 0.9) * vocab), 1)
+    top = lp.topk(k, dim=-1).indices
+    assert bool((top == tp[:, :, None]).any(-1).all())
+    assert not torch.equal(tp, lp.argmax(-1))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_sampled_decode_draws_do_not_depend_on_the_row_ranges(dtype):
     """A draw is keyed by (seed; row of the BATCH, position): two row ranges on two streams (the default for bf16 beyond 223 images,
