@@ -172,7 +172,10 @@ struct Engine : EngineBase {
     bool self_plain = getenv("TXO_SELF_FUSED") == nullptr;
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
-    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 257;   // narrow decoder: rows from which the folded out-projection runs on 32-row blocks
+    // narrow decoder, folded latent out-projection (K = heads * D): 32 x 32 blocks from wide_min_rows rows of a range on, 32 x 16 blocks from
+    // wide_mid_rows on (TXO_WIDE_MID_ROWS=100000 switches them off), 16 x 16 blocks below
+    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 257;
+    int wide_mid_rows = getenv("TXO_WIDE_MID_ROWS") ? atoi(getenv("TXO_WIDE_MID_ROWS")) : 129;
     bool kw24_off = getenv("TXO_KW24_OFF") != nullptr;    // experiment switch: FFN-out at K = 3072 on the run-time-K tile (three request groups) instead of the fixed one
     // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
     // measured +22 % for a plain 256x256 store epilogue at K = 768 (1.85 GB of output per launch), but the encoder's own epilogues
@@ -923,8 +926,11 @@ struct Engine : EngineBase {
             const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
             // narrow decoder: only the folded latent output projection (K = heads * D = 2048) of a beam search's many rows -- 640 rows are
             // 1280 16-row blocks of 128 KB each (19.6 us on one range; on two ranges of 320 rows the 32-row blocks give 1066 -> 1130 img/s).
-            // Up to 256 rows per range they change nothing (batch 256: 76.1 vs 76.4 ms on two ranges, 82.0 vs 81.5 on one)
-            if (D < 512 && !(kw == 16 && a.rows >= wide_min_rows && EPI == EPI_GLU_RES)) return false;
+            // Up to 256 rows per range they change nothing (batch 256: 76.1 vs 76.4 ms on two ranges, 82.0 vs 81.5 on one).  r05: 32 x 16 blocks
+            // for 129 .. 256 rows of ONE range (192 rows: 384 blocks of 16 x 16 are one and a half rounds of the CUs, 192 of 32 x 16 one):
+            // generate 60.3 -> 59.6 ms at 130 images, 64.7 -> 62.9 at 160, 68.6 -> 66.6 at 192; two ranges of <= 128 rows keep 16 x 16
+            // (75.5 ms at 256 against 79.0), profiles/r05_folded_projection_blocks.txt.  A row's bits do not depend on the block.
+            if (D < 512 && !(kw == 16 && a.rows >= std::min(wide_min_rows, wide_mid_rows) && EPI == EPI_GLU_RES)) return false;
             a.stamps = nullptr;
 #define TXO_DGW(KW_, BN_, RT_)                                                                                              \
             do {                                                                                                            \
@@ -933,7 +939,9 @@ struct Engine : EngineBase {
                 return true;                                                                                                \
             } while (0)
             if (kw == 6) TXO_DGW(6, 32, 4);                  // K = 768: the gated out-projections, FFN-in behind its LayerNorm launch
-            if constexpr (EPI == EPI_GLU_RES) { if (kw == 16) TXO_DGW(16, 32, 2); }   // (16 columns and / or 64 rows per block: 1080-1084 against 1134 img/s at the beam shape)
+            if constexpr (EPI == EPI_GLU_RES) {
+                if (kw == 16) { if (a.rows < wide_min_rows) TXO_DGW(16, 16, 2); TXO_DGW(16, 32, 2); }   // (at the beam shape, 320 rows per range: 16 columns and / or 64 rows per block 1080-1084 against 1134 img/s)
+            }
 #undef TXO_DGW
             return false;
         }
