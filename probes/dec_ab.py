@@ -1,5 +1,5 @@
 """Decode A/B of engines BUILT under different environments (knobs the engine reads once, at creation), interleaved in one process:
-   python probes/dec_ab.py <what> <B> "-" "TXO_LAT_NW=4" ...      what = greedy | sample | beam5   (bf16, 224x672, 256 positions)
+   python probes/dec_ab.py <what> <B> "-" "TXO_LAT_NW=4" ...      what = greedy | sample | beam5 | cfg4   (bf16, 224x672, 256 positions; cfg4 = greedy at the ViT-Base dims)
 Prints min / median ms per generate and whether the tokens equal the first configuration's."""
 import os, sys, time, statistics, hashlib
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ from texocr_amd.model import model_from_dims
 
 what, B, cfgs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 H, W, T = 224, 672, 256
-d = Dims(canvas=672)
+d = Dims(canvas=672, embed_dim=768, enc_heads=12, enc_layers=12, dec_heads=12, dec_layers=6) if what == "cfg4" else Dims(canvas=672)
 sd = synth.synth_state_dict(d, 0)
 rows = B * 5 if what == "beam5" else B
 ms = {}; envs = {}
@@ -24,7 +24,7 @@ for c in cfgs:
 torch.manual_seed(0)
 img = torch.rand((B, 3, H, W), device="cuda")
 def run(m):
-    if what == "greedy": return m.generate(img, T)
+    if what in ("greedy", "cfg4"): return m.generate(img, T)
     if what == "sample": return m.generate(img, T, decode="sample", temp=0.3, seed=7)
     return m.generate(img, T, beam=5)
 res = {c: [] for c in cfgs}; outs = {}
