@@ -140,7 +140,23 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
     constexpr int NF = KC <= 8 ? 2 : (NW == 4 ? 1 : 0);       // (4-wave tiles run one wave per SIMD: 512 registers; f32 at 8 waves: one set)
     u32x4 cur[KC], a1[NF >= 1 ? KC : 1], a2[NF == 2 ? KC : 1];
     (void)a1; (void)a2;
+    // Request shape (r05).  Fragment-shaped: instruction kc of a tile covers 16 rows x 64 B (lane = row lc, piece lg) -- the registers ARE the
+    // MFMA fragments, but every instruction touches 16 half-used 128-byte lines, and the CU's address path, not HBM, then bounds the stream
+    // (probes/xcd_bw.hip: 77 MB over 256 workgroups in 12.9 us with this shape against 9.8 us with whole lines).  Whole rows (COAL): instruction j
+    // covers RPI consecutive rows completely (lane = row j * RPI + lane / CPR, piece lane % CPR); the tile goes to the wave's LDS image as before
+    // and the score MFMAs take their fragments from the image.  Same values in the same MFMAs: the same bits.  The per-key slot tables of a beam
+    // search's self attention (a.path) keep the fragment shape (a lane would need eight slots per tile).
+    constexpr int CPR = ROWB / 16, RPI = CPR <= 64 ? 64 / CPR : 1;     // 16-byte pieces per row, rows per wave-instruction
+    constexpr bool COAL_OK = FAST && CPR <= 64 && 64 % CPR == 0 && KC == 16 / RPI;
+    const bool coal = COAL_OK && a.path == nullptr;
+    const int c_row = lane / CPR, c_ch = lane % CPR;
     auto issue = [&](int it, u32x4 (&dst)[KC]) {              // `it`-th tile of this wave: keys 16 * (wave + it * NW) ..
+        if (coal) {
+            const int k0 = (wave + it * NW) * 16 + c_row;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) dst[j] = ld16(eb + (size_t)min(k0 + j * RPI, last_key) * D_ + c_ch * PER16);
+            return;
+        }
         const int key = min((wave + it * NW) * 16 + lc, last_key);
         const T* p = eb + (size_t)key * D_ + lg * PER16;
         if (a.path) {                                         // (wave-uniform branch; the slot by a select chain: no run-time register indexing)
@@ -184,6 +200,16 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
     auto process = [&](int it, u32x4 (&e)[KC]) {
         const int t0 = (wave + it * NW) * 16;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (coal) {
+            // whole-row requests: registers -> image (row j * RPI + lane / CPR, piece lane % CPR), fragments <- image
+#pragma unroll
+            for (int j = 0; j < KC; ++j) st16(scr + la_off<ROWB, XM>(j * RPI + c_row, c_ch), e[j]);
+            asm volatile("" ::: "memory");
+            if constexpr (QF_REGS) {
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) mma16<T>(s, ld16(scr + la_off<ROWB, XM>(lc, 4 * kc + lg)), qf[kc]);
+            }
+        } else {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             if constexpr (QF_REGS) mma16<T>(s, e[kc], qf[kc]);
@@ -195,6 +221,7 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
         // the same registers -> the wave's LDS image (row = key lc, chunks 4 kc + lg)
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) st16(scr + la_off<ROWB, XM>(lc, 4 * kc + lg), e[kc]);
+        }
         asm volatile("" ::: "memory");
         // online softmax per head (lane column); this lane's keys: t0 + 4 lg + r
         float sv[4]; bool ok[4];
