@@ -205,9 +205,10 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
 #pragma unroll
             for (int j = 0; j < KC; ++j) st16(scr + la_off<ROWB, XM>(j * RPI + c_row, c_ch), e[j]);
             asm volatile("" ::: "memory");
-            if constexpr (QF_REGS) {
 #pragma unroll
-                for (int kc = 0; kc < KC; ++kc) mma16<T>(s, ld16(scr + la_off<ROWB, XM>(lc, 4 * kc + lg)), qf[kc]);
+            for (int kc = 0; kc < KC; ++kc) {
+                if constexpr (QF_REGS) mma16<T>(s, ld16(scr + la_off<ROWB, XM>(lc, 4 * kc + lg)), qf[kc]);
+                else mma16<T>(s, ld16(scr + la_off<ROWB, XM>(lc, 4 * kc + lg)), qfrag(kc));
             }
         } else {
 #pragma unroll
