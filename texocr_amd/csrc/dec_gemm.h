@@ -95,6 +95,9 @@ template <typename T> struct DecGemmArgs {
     // problem
     int rows, N, K;                 // rows = batch, W is [N][K]
     const T* W;
+    int w_tiled;                    // launch path (r05): W is the TILED copy -- the 16 rows x 64 B that one wave-instruction fetches as MFMA fragments lie
+                                    // contiguously ([n / 16][k-chunk][n % 16][64 B]; rows beyond N repeat row N - 1): whole 128-byte lines per request
+                                    // instead of 16 half lines (tile_weights_kernel).  0 = row-major (the persistent kernel, every other reader)
     const float* bias;              // interleaved order for the paired epilogues
     // prologue
     const T* A;                     // PRO_NONE: [rows][K]
@@ -157,7 +160,7 @@ __device__ inline int a_off(int r, int k, int row_bytes, int pmask) {
 // a 512-thread workgroup, each with its own `smem`).  valid = false: the group has no tile in this round -- it runs the same
 // barriers on clamped addresses and stores nothing.
 template <typename T, int KW, int BN>
-__device__ __forceinline__ void dec_gemm_prefetch(WBuf& f, const T* W, int N, int bx, int tid, bool real) {
+__device__ __forceinline__ void dec_gemm_prefetch(WBuf& f, const T* W, int N, int bx, int tid, bool real, int tiled = 0) {
     static_assert(KW > 0, "compile-time K only");
     constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK, K = KW * 4 * KCH;
     static_assert(wfrag_regs(KW, BN) <= WBUF_REGS, "prefetch buffer too small");
@@ -167,10 +170,17 @@ __device__ __forceinline__ void dec_gemm_prefetch(WBuf& f, const T* W, int N, in
     const int n0 = real ? bx * BN : 0;
     const T* w0 = W + (size_t)min(n0 + lr, N - 1) * K + lg * PER16;
     const T* w1 = W + (size_t)min(n0 + 16 + lr, N - 1) * K + lg * PER16;
+    int wstep = KCH;
+    if (tiled) {                                              // (DecGemmArgs::w_tiled)
+        const int nt = (N + 15) >> 4;
+        w0 = W + ((size_t)min(n0 >> 4, nt - 1) * (K / KCH) * 16 + lr) * KCH + lg * PER16;
+        w1 = W + ((size_t)min((n0 >> 4) + 1, nt - 1) * (K / KCH) * 16 + lr) * KCH + lg * PER16;
+        wstep = 16 * KCH;
+    }
 #pragma unroll
     for (int c = 0; c < KW; ++c) {
-        f.r[c] = ld16(w0 + (wave + 4 * c) * KCH);
-        if constexpr (BN == 32) f.r[KW + c] = ld16(w1 + (wave + 4 * c) * KCH);
+        f.r[c] = ld16(w0 + (size_t)(wave + 4 * c) * wstep);
+        if constexpr (BN == 32) f.r[KW + c] = ld16(w1 + (size_t)(wave + 4 * c) * wstep);
     }
 }
 
@@ -222,12 +232,19 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
     const int wr0 = min(na, a.N - 1), wr1 = min(nb, a.N - 1);
     const T* w0 = a.W + (size_t)wr0 * K + lg * PER16;
     const T* w1 = a.W + (size_t)wr1 * K + lg * PER16;
+    int wstep = KCH;                                          // elements between consecutive k-chunks of a row
+    if (a.w_tiled) {                                          // (kernel-uniform) tiled copy: chunk kc of row tile nt at ((nt * nch + kc) * 16 + lr) * KCH
+        const int nt = (a.N + 15) >> 4;
+        w0 = a.W + ((size_t)min(na >> 4, nt - 1) * nch * 16 + lr) * KCH + lg * PER16;
+        w1 = a.W + ((size_t)min(nb >> 4, nt - 1) * nch * 16 + lr) * KCH + lg * PER16;
+        wstep = 16 * KCH;
+    }
     u32x4 fw0[GROUP], fw1[GROUP], fa[GROUP];
     auto load_w = [&](int g0) {
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch) {
             const int kc = wave + 4 * (g0 + c);
-            fw0[c] = ld16_w<COH>(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16_w<COH>(w1 + kc * KCH);
+            fw0[c] = ld16_w<COH>(w0 + (size_t)kc * wstep); if constexpr (TWO) fw1[c] = ld16_w<COH>(w1 + (size_t)kc * wstep);
         }
     };
     auto load_a_global = [&](int g0) {
@@ -447,12 +464,19 @@ __device__ __forceinline__ void dec_gemm_wide_tile(const DecGemmArgs<T>& a, int 
     else if constexpr (EPI == EPI_BIAS_RES || EPI == EPI_LOGITS) { e_b0 = a.bias[min(na, a.N - 1)]; e_b1 = a.bias[min(nb, a.N - 1)]; }
     const T* w0 = a.W + (size_t)min(na, a.N - 1) * K + lg * PER16;
     const T* w1 = a.W + (size_t)min(nb, a.N - 1) * K + lg * PER16;
+    int wstep = KCH;
+    if (a.w_tiled) {                                          // (dec_gemm_tile_pf)
+        const int nt = (a.N + 15) >> 4;
+        w0 = a.W + ((size_t)min(na >> 4, nt - 1) * (K / KCH) * 16 + lr) * KCH + lg * PER16;
+        w1 = a.W + ((size_t)min(nb >> 4, nt - 1) * (K / KCH) * 16 + lr) * KCH + lg * PER16;
+        wstep = 16 * KCH;
+    }
     u32x4 fw0[GROUP], fw1[GROUP], fa[RT][GROUP];
     auto load_group = [&](int g0) {
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) {
             const int kc = wave + 4 * (g0 + c);
-            fw0[c] = ld16(w0 + kc * KCH); if constexpr (TWO) fw1[c] = ld16(w1 + kc * KCH);
+            fw0[c] = ld16(w0 + (size_t)kc * wstep); if constexpr (TWO) fw1[c] = ld16(w1 + (size_t)kc * wstep);
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -538,6 +562,19 @@ template <typename T, int EPI, int KW, int BN, int RT>
 __global__ __launch_bounds__(256, 1) void dec_gemm_wide_kernel(DecGemmArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     dec_gemm_wide_tile<T, EPI, KW, BN, RT>(a, blockIdx.x, blockIdx.y, threadIdx.x, smem);
+}
+
+// W [N][K] row-major -> the tiled copy (DecGemmArgs::w_tiled); one thread per 16-byte piece
+template <typename T>
+__global__ void tile_weights_kernel(const T* __restrict__ src, T* __restrict__ dst, int N, int K) {
+    constexpr int PER16 = Elem<T>::PER16, KCH = Elem<T>::KCHUNK;
+    const int nch = K / KCH;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)((N + 15) / 16) * nch * 64;
+    if (idx >= total) return;
+    const int lg = idx & 3, lr = (idx >> 2) & 15;
+    const size_t blk = idx >> 6;
+    const int kc = (int)(blk % nch), nt = (int)(blk / nch);
+    st16(dst + idx * PER16, ld16(src + (size_t)min(nt * 16 + lr, N - 1) * K + kc * KCH + lg * PER16));
 }
 
 template <typename T>

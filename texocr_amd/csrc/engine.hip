@@ -558,6 +558,19 @@ struct Engine : EngineBase {
         if (!(t = get("decoder.net.to_logits.bias", {V}))) return TXO_E_STATE;
         if (int r = upload_f32(&blog, t->data)) return r;
         host.clear();
+        if (w_tiled_on) {    // tiled copies of every weight the decode-step projections read (dec_gemm.h: w_tiled)
+            HIP_TRY(hipDeviceSynchronize());
+            const int H = c.dec_heads;
+            for (int l = 0; l < c.dec_layers; ++l) {
+                want_tiled(dec_self[l].wqkv, 3 * Id, D); want_tiled(dec_self[l].wo, 2 * D, Id);
+                want_tiled(dec_self[l].wqp, H * D, D); want_tiled(dec_self[l].wo_f, 2 * D, H * D);
+                want_tiled(dec_cross[l].wq, Id, D); want_tiled(dec_cross[l].wo, 2 * D, Id);
+                want_tiled(dec_cross[l].wqp, H * D, D); want_tiled(dec_cross[l].wo_f, 2 * D, H * D);
+                want_tiled(dec_mlp[l].w1, 2 * Fd, D); want_tiled(dec_mlp[l].w2, D, Fd);
+            }
+            want_tiled(wlog, V, D);
+            if (int r = make_tiled_all()) return r;
+        }
         ready = true;
         return 0;
     }
@@ -874,8 +887,47 @@ struct Engine : EngineBase {
         }
     }
 
+    // tiled copies of the decode projections' weights for the launch path (dec_gemm.h: w_tiled), keyed by the row-major buffer
+    std::map<const void*, T*> wtiled;
+    int w_tiled_on = getenv("TXO_W_TILED") ? atoi(getenv("TXO_W_TILED")) : 1;     // TXO_W_TILED=0: every projection reads the row-major buffers (A/B)
+    // one allocation for all of them (the arenas' reason: few large mappings); `want` collects (buffer, N, K), make_tiled_all() builds
+    struct TileReq { const T* w; int N, K; };
+    std::vector<TileReq> tile_reqs;
+    void want_tiled(const T* w, int N, int K) {
+        if (!w_tiled_on || !w || K % Elem<T>::KCHUNK) return;
+        for (auto& r : tile_reqs) if (r.w == w) return;
+        tile_reqs.push_back({w, N, K});
+    }
+    int make_tiled_all() {
+        if (tile_reqs.empty()) return 0;
+        auto pieces = [](const TileReq& r) { return (size_t)((r.N + 15) / 16) * (r.K / Elem<T>::KCHUNK) * 64; };   // 16-byte pieces
+        size_t total = 0;
+        for (auto& r : tile_reqs) total += (pieces(r) * 16 + 255) & ~(size_t)255;
+        unsigned char* base = nullptr;
+        HIP_TRY(hipMalloc(&base, total));
+        allocs.push_back(base);
+        size_t off = 0;
+        for (auto& r : tile_reqs) {
+            T* d = reinterpret_cast<T*>(base + off);
+            hipLaunchKernelGGL((tile_weights_kernel<T>), dim3((unsigned)((pieces(r) + 255) / 256)), dim3(256), 0, 0, r.w, d, r.N, r.K);
+            wtiled[r.w] = d;
+            off += (pieces(r) * 16 + 255) & ~(size_t)255;
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        tile_reqs.clear();
+        return 0;
+    }
+    void use_tiled(DecGemmArgs<T>& a) const {
+        a.w_tiled = 0;
+        if (!w_tiled_on) return;
+        auto it = wtiled.find(a.W);
+        if (it != wtiled.end()) { a.W = it->second; a.w_tiled = 1; }
+    }
+
     template <int PRO, int EPI>
     int launch_dec_gemm(hipStream_t s, DecGemmArgs<T> a) {
+        use_tiled(a);
         constexpr bool has_pro = PRO != PRO_NONE;
         // 16-column tiles (half the cold weight bytes per block, twice the blocks) where the block's traffic is its weight
         // slice: the out-projections and FFN-out (K >= 1024).  Launches with an LN prologue keep 32 columns: every block also
@@ -922,6 +974,7 @@ struct Engine : EngineBase {
         if constexpr (sizeof(T) != 2) { (void)s; (void)a; return false; }
         else {
             if (a.rows < 128 || dec_wide_off) return false;
+            use_tiled(a);
             constexpr int KCH = Elem<T>::KCHUNK;
             const int kw = (a.K % (4 * KCH) == 0) ? a.K / (4 * KCH) : 0;
             // narrow decoder: only the folded latent output projection (K = heads * D = 2048) of a beam search's many rows -- 640 rows are
@@ -1433,8 +1486,23 @@ struct Engine : EngineBase {
             L.wq_c = dec_cross[l].wq; L.wo_c = dec_cross[l].wo; L.bo_c = dec_cross[l].bo;
             L.w1 = dec_mlp[l].w1; L.b1 = dec_mlp[l].b1; L.w2 = dec_mlp[l].w2; L.b2 = dec_mlp[l].b2;
         }
+        pa.wlog = wlog;
+        {   // the projections' weights as their tiled copies (all of them, or none)
+            bool all = w_tiled_on && wtiled.count(wlog);
+            for (int l = 0; l < cfg.dec_layers && all; ++l)
+                all = wtiled.count(dec_self[l].wqkv) && wtiled.count(dec_self[l].wo) && wtiled.count(dec_cross[l].wo) && wtiled.count(dec_mlp[l].w1) && wtiled.count(dec_mlp[l].w2);
+            pa.w_tiled = all ? 1 : 0;
+            if (all) {
+                for (int l = 0; l < cfg.dec_layers; ++l) {
+                    PersistLayer<T>& L = pa.L[l];
+                    L.wqkv = wtiled.at(dec_self[l].wqkv); L.wo_s = wtiled.at(dec_self[l].wo); L.wo_c = wtiled.at(dec_cross[l].wo);
+                    L.w1 = wtiled.at(dec_mlp[l].w1); L.w2 = wtiled.at(dec_mlp[l].w2);
+                }
+                pa.wlog = wtiled.at(wlog);
+            }
+        }
         pa.gamma = dec_g; pa.beta = dec_b; pa.gamma_f = decn_g; pa.beta_f = decn_b; pa.tok_emb = tok_emb; pa.pos_emb = pos_emb;
-        pa.blog = blog; pa.wlog = wlog;
+        pa.blog = blog;
         pa.dx = dx; pa.dy = dy; pa.dq = dq; pa.dlogits = dlogits; pa.dao = dao; pa.dhid = dhid;
         pa.cur_tok = cur_tok; pa.eos_seen = eos_seen; pa.skv = skv; pa.ckv = ckv;
         pa.self_stride = (size_t)sB * Id * Tmax; pa.cross_stride = (size_t)sImg * N * Id;

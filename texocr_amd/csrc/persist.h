@@ -84,6 +84,7 @@ template <typename T> struct PersistArgs {
     int64_t* tokens_out; int out_stride; float* logits_out;
     PersistCtl* ctl;
     int poll_sleep;                                           // TeamSync: 64-clock sleeps between two polls of the flag line
+    int w_tiled;                                              // the projections' weights (wqkv, wo_s, wo_c, w1, w2, wlog) are the TILED copies (dec_gemm.h); wq_c stays row-major (dec_attn.h reads it)
     int sample; int sample_topk; float inv_temp; unsigned long long seed;   // sample != 0: the reference's sampler ends a position (step.h: sample_row) instead of the arg-max
     int early_mask;                                           // bit 0 / 1: the POLLING wave also requests its self-attention history / its cross K panel before the wait (its poll then returns behind them)
     int poll_mode;                                            // TeamSync::poll: 0 vector sc1 loads, 1 scalar glc loads, 2 the same behind s_dcache_inv, 3 (default) s_dcache_inv + plain scalar loads
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     const unsigned ln_lds_addr = (unsigned)(uintptr_t)ln_lds;     // low half of a generic LDS address = the LDS byte address
 
     DecGemmArgs<T> gb{};
-    gb.ln_lds = ln_lds_addr;
+    gb.ln_lds = ln_lds_addr; gb.w_tiled = a.w_tiled;
     gb.rows = nr; gb.gamma = a.gamma; gb.beta = a.beta; gb.t_ptr = nullptr; gb.D = D; gb.inner = ID; gb.heads = HEADS; gb.tmax = a.Tmax;
     float* lx = a.dx + (size_t)r0 * D; float* ly = a.dy + (size_t)r0 * D; float* lq = a.dq + (size_t)r0 * ID;
     T* lao = a.dao + (size_t)r0 * ID; T* lhid = a.dhid + (size_t)r0 * F; float* llog = a.dlogits + (size_t)r0 * a.V;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     constexpr bool PF_P = PS_AHEAD && KWP > 0 && wfrag_regs(KWP, 32) <= WBUF_REGS, PF_I = PS_AHEAD && KWI > 0 && wfrag_regs(KWI, 16) <= WBUF_REGS,
                    PF_F = PS_AHEAD && KWF > 0 && wfrag_regs(KWF, 16) <= WBUF_REGS;
     WBuf wbuf;
-    if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
+    if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV), a.w_tiled);
 
     // FFN-out (K = 4D: the longest weight rows of the step, 32 KB per tile) waited ~1.7 us per stage for its fragments to come
     // from the Infinity Cache (profiles/r02_persist_v6_stamps.txt: "reduce").  Its 16 tiles per layer are therefore pinned to
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
     if constexpr (W2_LDS_OK) {
         if (w2_lds && w2_layer < a.Ld) {
             WBuf park;
-            dec_gemm_prefetch<T, KWF, 16>(park, a.L[w2_layer].w2, D, w2_tile, tid, true);
+            dec_gemm_prefetch<T, KWF, 16>(park, a.L[w2_layer].w2, D, w2_tile, tid, true, a.w_tiled);
 #pragma unroll
             for (int c = 0; c < KWF; ++c) st16(w2_lds_base + ((size_t)c * 256 + tid) * 16, park.r[c]);
         }
@@ -385,14 +386,14 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
             const PersistLayer<T>& W = a.L[l];
             T* kc = a.skv + (size_t)(2 * l) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
             T* vc = a.skv + (size_t)(2 * l + 1) * a.self_stride + (size_t)r0 * HEADS * a.Tmax * DH;
-            auto pf_os = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_s, 2 * D, bx0(NC_O), tid, has0(NC_O)); };
-            auto pf_oc = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_c, 2 * D, bx0(NC_O), tid, has0(NC_O)); };
-            auto pf_f1 = [&]() { if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, W.w1, 2 * F, bx0(NC_F1), tid, has0(NC_F1)); };
-            auto pf_f2 = [&]() { if constexpr (PF_F) dec_gemm_prefetch<T, KWF, 16>(wbuf, W.w2, D, bx0(NC_F2), tid, has0(NC_F2)); };
+            auto pf_os = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_s, 2 * D, bx0(NC_O), tid, has0(NC_O), a.w_tiled); };
+            auto pf_oc = [&]() { if constexpr (PF_I) dec_gemm_prefetch<T, KWI, 16>(wbuf, W.wo_c, 2 * D, bx0(NC_O), tid, has0(NC_O), a.w_tiled); };
+            auto pf_f1 = [&]() { if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, W.w1, 2 * F, bx0(NC_F1), tid, has0(NC_F1), a.w_tiled); };
+            auto pf_f2 = [&]() { if constexpr (PF_F) dec_gemm_prefetch<T, KWF, 16>(wbuf, W.w2, D, bx0(NC_F2), tid, has0(NC_F2), a.w_tiled); };
             auto pf_next = [&]() {                            // behind the layer's last stage: next layer's q,k,v or the logits
                 if constexpr (PF_P) {
-                    if (l + 1 < a.Ld) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[l + 1].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
-                    else dec_gemm_prefetch<T, KWP, 32>(wbuf, a.wlog, a.V, bx0(nc_log), tid, has0(nc_log));
+                    if (l + 1 < a.Ld) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[l + 1].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV), a.w_tiled);
+                    else dec_gemm_prefetch<T, KWP, 32>(wbuf, a.wlog, a.V, bx0(nc_log), tid, has0(nc_log), a.w_tiled);
                 }
             };
             auto none = []() {};
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
         }
         if (ts.dead) break;
         auto pf_step = [&]() {                                // behind the logits: the next position's first q,k,v projection
-            if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV));
+            if constexpr (PF_P) dec_gemm_prefetch<T, KWP, 32>(wbuf, a.L[0].wqkv, 3 * ID, bx0(NC_QKV), tid, has0(NC_QKV), a.w_tiled);
         };
         {   // final LayerNorm + logits of this position (decoder.py:57-60)
             DecGemmArgs<T> g = gb; g.N = a.V; g.K = D; g.W = a.wlog; g.bias = a.blog; g.logits = llog; g.y = ly;
