@@ -118,6 +118,8 @@ template <typename T> struct DecGemmArgs {
                                     // position t of [rows][tmax][K] -- the self attention's history in latent form (lat_attn.h)
     float* logits;                  // [rows][N]
     unsigned long long* stamps;     // diagnostic (TXO_STAMPS): per block {entry, operands landed, exit} in 10 ns ticks; null normally
+    int a_tiled;                    // PRO_NONE, launch path: A is tiled like W ([m / 16][k-chunk][m % 16][64 B]) by its producer (lat_core's c output).  LAST member on
+                                    // purpose: the persistent kernel's code generation follows this struct's layout, and its speed moves by 2 % with it
 };
 
 constexpr int DG_BM = 16, DG_BN = 32, DG_GROUP = 8;   // DG_GROUP: k-chunks a wave keeps in flight at once
@@ -249,9 +251,12 @@ __device__ __forceinline__ void dec_gemm_tile_pf(const DecGemmArgs<T>& a, int bx
     };
     auto load_a_global = [&](int g0) {
         const int m = min(m0 + lr, rows - 1);
+        const bool at = !COH && a.a_tiled;                   // (the persistent kernel's activations are row-major: its code is left as it was)
+        const size_t abase = at ? ((size_t)(m >> 4) * nch * 16 + (m & 15)) * KCH : (size_t)m * K;
+        const int astep = at ? 16 * KCH : KCH;
 #pragma unroll
         for (int c = 0; c < GROUP; ++c) if (g0 + c < my_nch)
-            fa[c] = ldc16_at<COH>(a.A, (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+            fa[c] = ldc16_at<COH>(a.A, abase + (size_t)(wave + 4 * (g0 + c)) * astep + lg * PER16);
     };
     if constexpr (HASPRE) {
         static_assert(FIXED && wfrag_regs(KW, BN) <= WBUF_REGS, "prefetched fragments need a compile-time K that fits the buffer");
@@ -482,7 +487,9 @@ __device__ __forceinline__ void dec_gemm_wide_tile(const DecGemmArgs<T>& a, int 
         for (int rt = 0; rt < RT; ++rt) {
             const int m = min(m0 + rt * DG_BM + lr, rows - 1);
 #pragma unroll
-            for (int c = 0; c < GROUP; ++c) fa[rt][c] = ld16(a.A + (size_t)m * K + (wave + 4 * (g0 + c)) * KCH + lg * PER16);
+            for (int c = 0; c < GROUP; ++c)
+                fa[rt][c] = ld16(a.A + (a.a_tiled ? ((size_t)(m >> 4) * (K / KCH) * 16 + (m & 15)) * KCH + (size_t)(wave + 4 * (g0 + c)) * (16 * KCH)
+                                                  : (size_t)m * K + (wave + 4 * (g0 + c)) * KCH) + lg * PER16);
         }
     };
     load_group(0);

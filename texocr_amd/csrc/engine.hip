@@ -650,7 +650,7 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dqt, (size_t)Bmax * Imax)) return r;
         if (int r = dalloc(&zc, (size_t)c.dec_layers * Bmax * Tmax * D)) return r;
         if (int r = dalloc(&dqp, (size_t)Bmax * c.dec_heads * D)) return r;
-        if (int r = dalloc(&dcl, (size_t)Bmax * c.dec_heads * D)) return r;
+        if (int r = dalloc(&dcl, ((size_t)Bmax + 16 * 4) * c.dec_heads * D)) return r;   // (+ tile alignment of the lanes' regions: c_base_row)
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
@@ -1081,13 +1081,19 @@ struct Engine : EngineBase {
     // the latent core over lane li's rows: q' in dqp, c to dcl.  Cross attention: enc = the session's encoder rows of the lane's first image,
     // len = sN, every beam of an image reads the same rows (kv_div).  Self attention: enc = the lane's rows of the z history of one layer,
     // enc_rows = Tmax, len = position + 1 (host value or *t_ptr), kv_div = 1, path = the beams' slot tables (or null).
+    // The latent core's output c feeds the folded output projection as its A operand: written in that GEMM's tiled layout (dec_gemm.h: a_tiled)
+    // when the core serves the CROSS attention with folded weights.  A lane's region starts on a 16-row tile boundary and lanes do not overlap.
+    int a_tiled_on = getenv("TXO_A_TILED") ? atoi(getenv("TXO_A_TILED")) : 1;
+    size_t c_base_row(int li) const { return ((lanes[li].b0 + 15) / 16) * 16 + (size_t)16 * li; }
+    bool c_tiled(int l, bool cross) const { return a_tiled_on && w_tiled_on && cross && dec_cross[l].wqp != nullptr && (D * (int)sizeof(T)) % 64 == 0; }
     void launch_lat_core(hipStream_t s, int li, int kv_div, const T* enc, int len, int enc_rows, const int* t_ptr, const short* path,
-                         const char* stamp_name, bool cross) {
+                         const char* stamp_name, bool cross, int layer = 0) {
         const Lane& ln = lanes[li];
         const size_t r0 = ln.b0;
         const int H = cfg.dec_heads, HD = H * D;
         LatCoreArgs<T> a{};
         a.qp = dqp + r0 * HD; a.c = dcl + r0 * HD; a.enc = enc;
+        if (c_tiled(layer, cross)) { a.c = dcl + c_base_row(li) * HD; a.c_hpr = H; }
         a.rows = ln.nb; a.heads = H; a.G = latent_group(sB, n_cus); a.ngrp = (H + a.G - 1) / a.G; a.len = len; a.kv_div = kv_div;
         a.enc_rows = enc_rows; a.t_ptr = t_ptr; a.path = path; a.path_stride = Tmax;
         int nimg = (ln.nb + kv_div - 1) / kv_div;
@@ -1156,7 +1162,7 @@ struct Engine : EngineBase {
             launch_grp_gemm<DH>(s, dqt + r0 * Id, Id, dec_cross[l].wkT, dqp + r0 * HD, HD, ln.nb, HD, D);
         }
         // 3. c_h = softmax_n(q'_h . enc[n]) enc
-        launch_lat_core(s, li, kv_div, enc_t + (r0 / kv_div) * (size_t)sN * D, sN, 0, nullptr, nullptr, "attn cross (latent core)", true);
+        launch_lat_core(s, li, kv_div, enc_t + (r0 / kv_div) * (size_t)sN * D, sN, 0, nullptr, nullptr, "attn cross (latent core)", true, l);
         if (fold) return 0;                                       // 4+5: the gated output projection takes c directly (K = heads*D, Wo' folded at load)
         // 4. o_h = c_h Wv_h^T ; 'b h n d -> b n (h d)'
         if (D == 64) launch_grp_gemm<64>(s, dcl + r0 * HD, HD, dec_cross[l].wv, dao + r0 * Id, Id, ln.nb, Id, DH);
@@ -1228,7 +1234,10 @@ struct Engine : EngineBase {
                 dbg(s, "cross attn", l);
                 DecGemmArgs<T> g = base; g.N = 2 * D; g.K = Id; g.W = dec_cross[l].wo; g.bias = dec_cross[l].bo; g.A = lao;
                 g.resid = lx; g.y_out = ly;
-                if (fold) { g.K = cfg.dec_heads * D; g.W = dec_cross[l].wo_f; g.A = dcl + r0 * cfg.dec_heads * D; }
+                if (fold) {
+                    g.K = cfg.dec_heads * D; g.W = dec_cross[l].wo_f; g.A = dcl + r0 * cfg.dec_heads * D;
+                    if (c_tiled(l, true)) { g.A = dcl + c_base_row(li) * cfg.dec_heads * D; g.a_tiled = 1; }
+                }
                 if (!launch_dec_gemm_wide<EPI_GLU_RES>(s, g)) { if (int r = launch_dec_gemm<PRO_NONE, EPI_GLU_RES>(s, g)) return r; }
                 dbg(s, "cross out", l);
             }

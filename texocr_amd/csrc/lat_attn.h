@@ -56,6 +56,9 @@ template <typename T> struct LatCoreArgs {
     int enc_rows;                         // rows per image of `enc` (0 = len)
     const int* t_ptr;
     const short* path; int path_stride;
+    // c in the tiled layout of dec_gemm's A operand (DecGemmArgs::a_tiled): output row m = row * (heads / c_hpr) + head / c_hpr, column
+    // k = (head % c_hpr) * D + d of a [.][c_hpr * D] matrix; c_hpr = 0: row-major [rows][heads * D]
+    int c_hpr;
     unsigned long long* stamps;           // diagnostic: per tile {entry, last key tile done, exit}
 };
 
@@ -332,6 +335,11 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
                 den = fmaf(e, st_l[w * 16 + h], den);
             }
             T* dst = crow + (size_t)hb * D_ + idx;
+            if (a.c_hpr) {                                    // (kernel-uniform) tiled: 4 consecutive d stay inside one 64-byte chunk
+                const int hh = h0 + h, m = img * (a.heads / a.c_hpr) + hh / a.c_hpr, k = (hh % a.c_hpr) * D_ + (idx % D_);
+                constexpr int KCHT = 64 / (int)sizeof(T);
+                dst = a.c + (((size_t)(m >> 4) * (a.c_hpr * D_ / KCHT) + (k / KCHT)) * 16 + (m & 15)) * KCHT + (k % KCHT);
+            }
             if constexpr (sizeof(T) == 2) {
                 uint2 o; o.x = pack_bf16x2(num[0] / den, num[1] / den); o.y = pack_bf16x2(num[2] / den, num[3] / den);
                 *reinterpret_cast<uint2*>(dst) = o;
