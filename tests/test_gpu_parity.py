@@ -1667,6 +1667,36 @@ def test_latent_tile_head_group_size_does_not_change_a_heads_bits():
             del m
 
 
+def test_tiled_weights_and_whole_row_requests_do_not_change_a_bit():
+    """Round 5 changed the SHAPE of three kinds of memory requests, never their values: the decode projections read tiled copies of their
+    weights (dec_gemm.h: w_tiled; also inside the persistent launch), the latent core writes its output in the folded projection's tiled A
+    layout (a_tiled) and fetches whole encoder rows.  Engines built with TXO_W_TILED=0 / TXO_A_TILED=0 (row-major everywhere) must return
+    bit-identical tokens and logits: persistent launch and launches at batch 7, the latent launch path incl. a beam search at row counts
+    that are not multiples of 16 (37 rows; 185 beam rows), both storage types."""
+    d = Dims(canvas=224)
+    img = torch.from_numpy(synth.synth_images(37, 3, 64, 160, seed=9)).cuda()
+    for dtype in ("bf16", "fp32"):
+        ref = None
+        for env in (None, {"TXO_W_TILED": "0"}, {"TXO_A_TILED": "0"}):
+            _, _, m = build(d, seed=5, dtype=dtype, max_batch=185, env=env)
+            m.eos_token = None
+            (tp, lp), (tl, ll) = _both_paths(m, img[:7], 24, return_logits=True)
+            assert torch.equal(tp, tl) and torch.equal(lp, ll)
+            del m
+            _, _, m = build(d, seed=5, dtype=dtype, max_batch=185, latent=1, env=env)
+            m.eos_token = None
+            lat = m.generate(img, 24, return_logits=True)
+            assert m._engine.query(3) == 1
+            beams = m.generate(img, 16, beam=5, return_beams=True)
+            out = (tp, lp, lat[0], lat[1], beams[0], beams[1])
+            if ref is None:
+                ref = out
+            else:
+                for a, b in zip(out, ref):
+                    assert torch.equal(a, b), (dtype, env)
+            del m
+
+
 def test_bf16_benchmark_shape_free_running_inside_batch_256_default_path():
     """The reference fixture of the benchmark's shape (cfg2_b2_224x672_t256) as rows 200 and 33 of a 256-image bf16 batch on the DEFAULT
     path at that size -- launches, cross attention in latent form, two row ranges on two streams, head groups of 8: the rows follow the
