@@ -24,14 +24,16 @@
 // size below 129, also inside the persistent kernel: profiles/r04_latent_in_tile_*.)
 //
 // lat_core tile = (row, group of G <= LA_GMAX = 16 heads: the 16 columns of the MFMA tile) by NW waves (8 at D <= 256, 4 above):
-//   keys are dealt to the waves in 16-key tiles.  Per tile: S^T[key][head] = enc_tile q'^T with the enc fragments straight from
-//   global memory in registers (A operand: a lane's 16-byte piece is a fragment); the same registers are written to a wave-private
-//   LDS image and read back TRANSPOSED (bf16: ds_read_b64_tr_b16) as the A operand of c^T[d][head] += enc_tile^T P^T; the P
-//   accumulator tile in its C layout IS the B operand (no lane movement).  Online softmax per head = per lane column.  Heads sit
+//   keys are dealt to the waves in 16-key tiles.  Per tile: the encoder rows are requested as WHOLE rows (bf16, r05: 2 x 512 B per
+//   wave-instruction; fragment-shaped requests -- 16 rows x 64 B -- are bound by the CU's address path, see `coal` below), written to a
+//   wave-private LDS image, S^T[key][head] = enc_tile q'^T takes its A fragments from the image, and the image is read back TRANSPOSED
+//   (bf16: ds_read_b64_tr_b16) as the A operand of c^T[d][head] += enc_tile^T P^T; the P accumulator tile in its C layout IS the B
+//   operand (no lane movement).  (fp32, and the per-key slot tables of a beam search's self attention: the registers are the fragments.)  Online softmax per head = per lane column.  Heads sit
 //   on the MFMA column: 16 columns, G of them used (a beam search packs an image's k x heads heads 16 to a tile).  The waves' (m, l, c)
 //   are merged through LDS.
 // A head's arithmetic does not depend on G or on which tile computed it.
 // Algorithmic bytes per launch = rows * N * D * sizeof(T) (+ q' and c: 2 * rows * heads * D * sizeof(T)).  Bound: HBM.
+// The output c is row-major [rows][heads * D], or -- for the folded output projection on the launch path -- in that GEMM's tiled A layout (c_hpr).
 #pragma once
 #include "common.h"
 #include "dec_attn.h"
