@@ -174,7 +174,7 @@ struct Engine : EngineBase {
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr, conv1x1_old = getenv("TXO_CONV1X1_OLD") != nullptr;
     // narrow decoder, folded latent out-projection (K = heads * D): 32 x 32 blocks from wide_min_rows rows of a range on, 32 x 16 blocks from
     // wide_mid_rows on (TXO_WIDE_MID_ROWS=100000 switches them off), 16 x 16 blocks below
-    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 257;
+    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 100000;   // (257 until the tiled operands: at a beam search's 320 rows per range 32 x 16 is now ahead, 98.5 vs 100.5 ms)
     int wide_mid_rows = getenv("TXO_WIDE_MID_ROWS") ? atoi(getenv("TXO_WIDE_MID_ROWS")) : 129;
     bool kw24_off = getenv("TXO_KW24_OFF") != nullptr;    // experiment switch: FFN-out at K = 3072 on the run-time-K tile (three request groups) instead of the fixed one
     // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
