@@ -211,6 +211,7 @@ struct Engine : EngineBase {
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     int enc_walk = getenv("TXO_ENC_WALK") ? atoi(getenv("TXO_ENC_WALK")) : 1;   // encoder kernels walk the rows alternately up and down (encode()); 0 = all upwards
     int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
+    int pp_sb_mb = getenv("TXO_PP_SB_MB") ? atoi(getenv("TXO_PP_SB_MB")) : PP_SB_MB;   // ... its row super-blocks: MB of A per super-block, 0 = none (gemm_pp.h)
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
@@ -684,7 +685,7 @@ struct Engine : EngineBase {
     template <class Epi>
     void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi, int rev = 0) {
         if constexpr (sizeof(T) == 2) {
-            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr, rev); return; }
+            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr, rev, pp_sb_mb); return; }
         }
         launch_gemm_big<T>(s, LoadPlain<T>{A, K}, W, M, N, K, epi);
     }
@@ -757,9 +758,31 @@ struct Engine : EngineBase {
         const int h = H / 16, w = W / 16, hw = h * w, N = hw + 1;
         if (B < 1 || B > Bmax) return fail(TXO_E_INVALID, "batch exceeds engine max_batch");
         if (N > Nmax) return fail(TXO_E_INVALID, "token count exceeds engine max_tokens");
-        const int M = B * N, G = cfg.canvas_w / 16;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (prof) { e0 = pool.next(); e1 = pool.next(); (void)hipEventRecord(e0, s); }
+        // Image chunks (enc_chunk_images): every row of the stack belongs to ONE image, so the stack may run over a few images at a time
+        // through the SAME workspace rows -- a chunk whose intermediates (stream, z, q/k/v, attention output, FFN hidden) fit the 256 MB
+        // Infinity Cache keeps every producer -> consumer hand-over on the die instead of through HBM.  Same bits as the whole batch.
+        const int bc = enc_chunk_images(B, N);
+        for (int b0 = 0; b0 < B; b0 += bc) {
+            const int nb = std::min(bc, B - b0);
+            if (int r = encode_images(img + (size_t)b0 * C * H * W, nb, C, H, W, enc_out + (size_t)b0 * N * D, s)) return r;
+        }
+        if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // images per encoder chunk: TXO_ENC_CHUNK=n forces n (0 = whole batch); default by measured working set (profiles/r06_encoder_chunk_sweep.txt)
+    int enc_chunk_env = getenv("TXO_ENC_CHUNK") ? atoi(getenv("TXO_ENC_CHUNK")) : -1;
+    int enc_chunk_images(int B, int N) const {
+        if (enc_chunk_env == 0) return B;
+        if (enc_chunk_env > 0) return std::min(B, enc_chunk_env);
+        (void)N;
+        return B;
+    }
+    int encode_images(const float* img, int B, int C, int H, int W, float* enc_out, hipStream_t s) {
+        const int h = H / 16, w = W / 16, hw = h * w, N = hw + 1;
+        const int M = B * N, G = cfg.canvas_w / 16;
 
         hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, ex, cls, pos, B, N, D);
         if (!hybrid) {
@@ -807,8 +830,6 @@ struct Engine : EngineBase {
             gemm_plain(s, ehid, enc_mlp[l].w2, M, D, Fe, EpiBiasRes{ey, res_x, enc_mlp[l].b2, nt_y}, dir());
         }
         launch_ln<2, float>(s, ey, nullptr, enc_out, encn_g, encn_b, M, dir());
-        if (prof) { (void)hipEventRecord(e1, s); ev_enc.push_back({e0, e1}); }
-        HIP_TRY(hipGetLastError());
         return 0;
     }
 

@@ -38,6 +38,7 @@ constexpr int PP_BUF_BYTES = 2 * PP_TILE_BYTES;       // A + W
 constexpr int PP_LDS_BYTES = 2 * PP_BUF_BYTES;        // two buffers = 128 KiB
 constexpr int PP_STAGE_BYTES = 8 * 4096;              // epilogue staging, 4 KiB per wave
 constexpr int PP_SMEM_BYTES = PP_LDS_BYTES + PP_STAGE_BYTES;   // 160 KiB: the whole LDS of a CU
+constexpr int PP_SB_MB = 64;                          // A bytes of a row super-block (tile walk below), MB
 
 // LDS-DMA of 16 bytes per lane: LDS destination = lds_base (wave-uniform) + lane * 16
 __device__ inline void dma16(const void* gsrc, unsigned char* lds_base) {
@@ -60,7 +61,7 @@ __device__ unsigned long long g_pp_dbg[4096];      // probes/pp_bench.hip: block
 // no LDS (comment at the epilogue below).  TR = false is the LDS-staged epilogue (kept for A/B: TXO_PP_TR=0, probes/pp_epi_bench.hip).
 template <class Epi, bool TR>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __restrict__ A, const bf16* __restrict__ W, int M, int N,
-                                                                int K, int tiles_n, int n_tiles, int ct, int rev, Epi epi) {
+                                                                int K, int tiles_n, int n_tiles, int ct, int sbr, int rev, Epi epi) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];     // ONE array: [buf][A|W][row*128] + epilogue staging
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,12 +79,19 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pp_kernel(const bf16* __re
     int n_my = 0;
     while (tile_seq(n_my) < n_tiles) ++n_my;
     if (n_my == 0) return;
-    const int tiles_m = n_tiles / tiles_n, band_tiles = tiles_m * ct;
+    // Row super-blocks (r06): with more than one band every band re-reads ALL of A, and at batch 256 an A operand (231 MB at the ViT-Base
+    // FFN-in) does not survive in the 256 MB Infinity Cache from one band to the next -- five of its six passes came from HBM.  The bands
+    // therefore run inside super-blocks of `sbr` row panels (A of a super-block ~64 MB: the passes after the first are Infinity-Cache hits).
+    // The persistent stream runs on across super-blocks, so unlike launching the GEMM per image chunk this costs no tail.
+    const int tiles_m = n_tiles / tiles_n, sb_tiles = sbr * tiles_n;
     auto tile_origin = [&](int seq, int& m0, int& n0) {
-        const int L = tile_seq(seq);
+        int L = tile_seq(seq);
+        const int sb = L / sb_tiles; L -= sb * sb_tiles;
+        const int band_tiles = min(sbr, tiles_m - sb * sbr) * ct;                        // the last super-block may be shorter
         const int band = L / band_tiles, k = L - band * band_tiles;
         const int cols = min(ct, tiles_n - band * ct);                                   // the last band may be narrower
         int row = k / cols; const int col = k - row * cols;
+        row += sb * sbr;
         if (rev) row = tiles_m - 1 - row;                                                // the row panels top down (engine.hip: encode)
         m0 = row * PP_BM; n0 = (band * ct + col) * PP_BN;
     };
@@ -382,7 +390,7 @@ inline bool gemm_pp_fits(int M, int N, int K) {
 // The engine reads TXO_PP_TR once per engine and passes it here (tests build engines with each form and compare them bit for bit).
 
 template <class Epi, bool TR>
-inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int rev) {
+inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int rev, int sb_mb) {
     const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
     const int n_tiles = tiles_m * tiles_n;
     // persistent grid: one block per CU (128-160 KiB LDS each).  Both the CU count and the > 64 KiB dynamic-LDS opt-in are per
@@ -409,13 +417,16 @@ inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M,
     static const int ct_env = [] { const char* e = getenv("TXO_PP_CT"); return e ? atoi(e) : 0; }();
     if (ct_env > 0) ct = std::max(1, std::min(tiles_n, ct_env));
     // narrower last band: when tiles_n % ct != 0 the row-major walk of the last band uses its own width (tile_origin)
+    // row super-block (kernel comment): only where there is more than one band; sb_mb = MB of A per super-block (0 = one super-block)
+    int sbr = tiles_m;
+    if (ct < tiles_n && sb_mb > 0) sbr = (int)std::max<long long>(8, std::min<long long>(tiles_m, ((long long)sb_mb << 20) / ((long long)PP_BM * K * 2)));
     const int grid = ((std::min(n_tiles, cus) + 7) / 8) * 8;
-    hipLaunchKernelGGL((gemm_pp_kernel<Epi, TR>), dim3(grid), dim3(PP_THREADS), smem, s, A, W, M, N, K, tiles_n, n_tiles, ct, rev, epi);
+    hipLaunchKernelGGL((gemm_pp_kernel<Epi, TR>), dim3(grid), dim3(PP_THREADS), smem, s, A, W, M, N, K, tiles_n, n_tiles, ct, sbr, rev, epi);
 }
 template <class Epi>
-inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1, int rev = 0) {
+inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1, int rev = 0, int sb_mb = PP_SB_MB) {
     if (tr < 0) tr = Epi::HAS_ROW ? 0 : 1;
-    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi, rev); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi, rev);
+    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi, rev, sb_mb); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi, rev, sb_mb);
 }
 
 }  // namespace txo
