@@ -134,6 +134,18 @@ int txo_generate_beam(txo_engine* e, const float* img_dev, int32_t B, int32_t C,
  * how the engine splits the batch into row ranges; a different stream than torch.multinomial. */
 int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint64_t seed);
 
+/* Where a decode stops -- the eos handling of txo_generate / txo_generate_from_enc (AutoRegressiveDecoder.generate, decoder.py:97-118).
+ * TXO_STOP_GLOBAL (default) is the reference: rows keep producing tokens after their eos and the loop breaks only when EVERY row contains
+ * eos (decoder.py:115-116).  TXO_STOP_ROW is a BUILD EXTENSION: a row that has produced eos is finished -- every later token
+ * of that row in tokens_out is cfg.pad -- and the loop still ends at the position at which the last row produced its eos, so *n_steps_out
+ * and every row's tokens up to and including its first eos are exactly TXO_STOP_GLOBAL's.  What changes is the cost: beyond 128 rows (one launch per
+ * stage) the live rows of a row range are compacted to its front every few positions and the launches shrink with them.  Rows whose
+ * BOS equals eos are finished from the start.  Not combined with logits_out (a finished row's logits are unspecified: no compaction then)
+ * and not applied to txo_generate_beam (a finished beam already costs nothing there). */
+#define TXO_STOP_GLOBAL 0
+#define TXO_STOP_ROW 1
+int txo_set_stop_mode(txo_engine* e, int32_t mode);
+
 /* Timing hooks for bench.py: average duration (ms) of the decode-step cross-attention launches and of
  * the encoder launches recorded with HIP events on the stream the kernels run on, since profiling was last
  * enabled (txo_profile_enable(e, 1) also clears the previous samples); *count = number of launches averaged.  kind: 0 = cross-attention decode kernel,
@@ -156,6 +168,7 @@ int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count
 #define TXO_Q_LAST_LATENT 3       /* 1 if the last generate's cross attention ran in latent form (csrc/lat_attn.h: against the raw encoder rows) */
 #define TXO_Q_RELOAD_KNOBS 4      /* not a question: re-read the TXO_* development knobs of generate() from the environment (the engine reads them once,
                                    * at creation; tests flip TXO_PERSIST / TXO_LANES on a live engine).  *out = 0 */
+#define TXO_Q_LAST_COMPACTIONS 5   /* live-row compactions of the last txo_generate* (TXO_STOP_ROW on the launch path; 0 otherwise) */
 int txo_engine_query(txo_engine* e, int32_t what, int64_t* out);
 
 const char* txo_last_error(void);

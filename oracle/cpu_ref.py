@@ -271,10 +271,28 @@ def _all_rows_have_eos(output: torch.Tensor, eos: Optional[int]) -> bool:
     return eos is not None and bool((output == eos).any(dim=1).all())
 
 
+def pad_after_eos(output: torch.Tensor, T0: int, eos: Optional[int], pad: int) -> torch.Tensor:
+    """stop='row' -- a BUILD EXTENSION the reference does not have (its loop, decoder.py:97-118, only breaks globally and returns
+    whatever the finished rows kept producing): a row is finished at its first eos (start tokens included, as the test at :115 looks
+    at the whole output) and every token behind it is `pad`.  Rows are independent (attention.py:101-180 never mixes batch rows), so the
+    tokens up to each row's first eos -- and the position of the global break -- are the reference's.  output: (B, T0 + n) with the
+    start tokens; returns the (B, n) generated part."""
+    toks = output[:, T0:].clone()
+    if eos is None:
+        return toks
+    for b in range(output.shape[0]):
+        hits = (output[b] == eos).nonzero()
+        if hits.numel():
+            first = int(hits[0])                                            # column of the whole output
+            toks[b, max(first + 1 - T0, 0):] = pad
+    return toks
+
+
 @torch.no_grad()
 def generate_recompute(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
                        net_max_len: Optional[int] = None, collect_logits: bool = False, grid_w: Optional[int] = None,
-                       start_tokens: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
+                       start_tokens: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                       stop: str = "global", pad: int = 0):
     """The reference algorithm as written: full-prefix recompute each step, cross K/V
     re-projected each step, sliding window (ocr_model.py:46-66, decoder.py:77-122), with the
     sampler replaced by argmax (greedy; argmax survives top-k and softmax(/temp))."""
@@ -296,7 +314,7 @@ def generate_recompute(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], 
         output = torch.cat([output, nxt], dim=-1)                           # :111
         if _all_rows_have_eos(output, eos):                                 # :115
             break
-    toks = output[:, T0:]                                                   # :118
+    toks = output[:, T0:] if stop == "global" else pad_after_eos(output, T0, eos, pad)   # :118
     return (toks, torch.stack(steps, 1)) if collect_logits else toks
 
 
@@ -349,7 +367,7 @@ class CachedDecoder:
 
 @torch.no_grad()
 def generate_cached(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max_len: int,
-                    collect_logits: bool = False, enc: Optional[torch.Tensor] = None):
+                    collect_logits: bool = False, enc: Optional[torch.Tensor] = None, stop: str = "global", pad: int = 0):
     enc = encode(sd, img) if enc is None else enc
     B = enc.shape[0]
     dec = CachedDecoder(sd, enc)
@@ -364,7 +382,7 @@ def generate_cached(sd: SD, img: torch.Tensor, bos: int, eos: Optional[int], max
         output = torch.cat([output, tok[:, None]], dim=-1)
         if _all_rows_have_eos(output, eos):
             break
-    toks = output[:, 1:]
+    toks = output[:, 1:] if stop == "global" else pad_after_eos(output, 1, eos, pad)
     return (toks, torch.stack(steps, 1)) if collect_logits else toks
 
 

@@ -126,6 +126,29 @@ def test_eos_global_break():
     assert names["eos_is_bos"]["n_steps"] == 1
 
 
+def test_row_stop_is_the_reference_up_to_each_rows_first_eos():
+    """stop='row' (build extension; the reference has no such mode): against the tokens captured from the reference's global-break
+    loop, every row is identical up to and including its first eos, `pad` behind it, and the loop ends at the same step."""
+    meta, g = load_golden("eos_break")
+    d, sd, img = model_of(meta)
+    for case in meta["cases"]:
+        ref_tok = g[f"tokens_{case['name']}"]
+        for gen in (cpu_ref.generate_cached, cpu_ref.generate_recompute):
+            t = gen(sd, img, d.bos, case["eos"], meta["max_len"], stop="row", pad=d.pad).numpy()
+            assert t.shape == ref_tok.shape, case
+            for b in range(t.shape[0]):
+                if case["eos"] == d.bos:
+                    assert (t[b] == d.pad).all()
+                    continue
+                hits = np.nonzero(ref_tok[b] == case["eos"])[0]
+                n = int(hits[0]) + 1 if hits.size else t.shape[1]
+                assert np.array_equal(t[b, :n], ref_tok[b, :n]) and (t[b, n:] == d.pad).all(), (case, b)
+    # the rewrite on its own, start tokens included in the test (decoder.py:115 looks at the whole output)
+    out = torch.tensor([[5, 1, 2, 9, 3, 9], [5, 9, 1, 2, 3, 4], [9, 1, 2, 3, 4, 5], [5, 1, 2, 3, 4, 6]])
+    got = cpu_ref.pad_after_eos(out, 2, 9, 0)
+    assert got.tolist() == [[2, 9, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0], [2, 3, 4, 6]]
+
+
 def test_sliding_window_recompute_only():
     meta, g = load_golden("sliding_window")
     d, sd, img = model_of(meta)

@@ -39,6 +39,7 @@ SYMBOLS = {
     "txo_generate_from_enc": (C.c_int, [_P, _FP, _I, _I, _I, _I, _I64P, C.POINTER(C.c_int32), _FP, _P]),
     "txo_generate_beam": (C.c_int, [_P, _FP, _I, _I, _I, _I, _I, _I, _I, _I64P, _FP, _I64P, C.POINTER(C.c_int32), _P]),
     "txo_set_sampling": (C.c_int, [_P, _I, _I, C.c_float, C.c_uint64]),
+    "txo_set_stop_mode": (C.c_int, [_P, _I]),
     "txo_profile_enable": (C.c_int, [_P, _I]),
     "txo_profile_read": (C.c_int, [_P, _I, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "txo_engine_query": (C.c_int, [_P, _I, C.POINTER(C.c_int64)]),

@@ -74,6 +74,7 @@ struct EngineBase {
                               int eos, int64_t* tokens_out, float* scores_out, int64_t* all_tokens_out, int* n_steps,
                               hipStream_t s) = 0;
     int sample_mode = 0, sample_topk = 0; float sample_temp = 1.f; unsigned long long sample_seed = 0;
+    int stop_mode = 0;                          // txo_set_stop_mode: 0 = the reference's global eos break only, 1 = per-row stop (pad behind a row's first eos)
     virtual int query(int what, int64_t* out) = 0;
     virtual int profile_enable(int on) = 0;
     virtual int profile_read(int kind, double* avg_ms, int64_t* count) = 0;
@@ -215,6 +216,13 @@ struct Engine : EngineBase {
     bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
+    // per-row stop (step.h): batch row held by every slot of a row range, scratch of the compaction, {live rows, moves} per range;
+    // live_host (pinned): the ranges' finished-row counts on their way to the host, ev_live behind them
+    int *row_map = nullptr, *row_map2 = nullptr, *cmoves = nullptr, *cinfo = nullptr; int64_t* cur_tok2 = nullptr;
+    int* live_host = nullptr; hipEvent_t ev_live[MAXL] = {};
+    int stop_every = getenv("TXO_STOP_EVERY") ? std::max(1, atoi(getenv("TXO_STOP_EVERY"))) : 16;   // positions between two looks at the live-row counts
+    int stop_gain = getenv("TXO_STOP_GAIN") ? std::max(1, atoi(getenv("TXO_STOP_GAIN"))) : 16;      // rows a compaction must free (one 16-row tile)
+    int last_compactions = 0;         // compactions of the last generate (TXO_Q_LAST_COMPACTIONS)
     bool look_failed = false;
     int step_host_t = -1;             // position of the step being enqueued when the host knows it (see enqueue_step)
     // TXO_STAMPS=<file>: diagnostic -- every decode launch of ONE step records per-block entry / mid / exit times
@@ -259,7 +267,9 @@ struct Engine : EngineBase {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         for (auto e : ev_join) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_flags) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_live) if (e) (void)hipEventDestroy(e);
         if (flags_host) (void)hipHostFree(flags_host);
+        if (live_host) (void)hipHostFree(live_host);
         if (pctl_host) (void)hipHostFree(pctl_host);
         for (void* p : allocs) (void)hipFree(p);
     }
@@ -594,6 +604,8 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_join[i], hipEventDisableTiming));
         for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_flags[i], hipEventDisableTiming));
+        for (int i = 0; i < MAXL; ++i) HIP_TRY(hipEventCreateWithFlags(&ev_live[i], hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&live_host), sizeof(int) * MAXL, hipHostMallocDefault));
         return 0;
     }
     int init_buffers() {
@@ -655,6 +667,11 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
+        if (int r = dalloc(&row_map, (size_t)Bmax)) return r;
+        if (int r = dalloc(&row_map2, (size_t)Bmax)) return r;
+        if (int r = dalloc(&cur_tok2, (size_t)Bmax)) return r;
+        if (int r = dalloc(&cmoves, (size_t)2 * Bmax)) return r;
+        if (int r = dalloc(&cinfo, (size_t)2 * MAXL)) return r;
         if (int r = dalloc(&kmask, (size_t)Bmax * Tmax)) return r;
         if (int r = dalloc(&done_flag, (size_t)Tmax * MAXL)) return r;
         if (int r = dalloc(&st, MAXL)) return r;
@@ -905,6 +922,7 @@ struct Engine : EngineBase {
             const int n = ln.nb > Tmax ? ln.nb : Tmax;
             hipLaunchKernelGGL(reset_state_kernel, dim3((n + 255) / 256), dim3(256), 0, s, st + i, cur_tok + ln.b0,
                                eos_seen + ln.b0, done_flag + (size_t)i * Tmax, ln.nb, Tmax, cfg.bos, eos);
+            if (row_stop) hipLaunchKernelGGL(iota_kernel, dim3((ln.nb + 255) / 256), dim3(256), 0, s, row_map + ln.b0, ln.nb, ln.b0);
         }
     }
 
@@ -1289,7 +1307,8 @@ struct Engine : EngineBase {
         dbg(s, "logits");
         StepArgs sa{llog, V, nb, cur_tok + r0, tokens_out ? tokens_out + r0 * out_stride : nullptr, out_stride,
                     logits_out ? logits_out + r0 * (size_t)out_stride * V : nullptr, st + li, eos_seen + r0,
-                    done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp, sample_seed, (int)r0};
+                    done_flag + (size_t)li * Tmax, eos, sample_topk, 1.0f / sample_temp, sample_seed, (int)r0,
+                    row_stop ? 1 : 0, row_stop ? row_map + r0 : nullptr};
         if (bm) {
             BeamArgs ba{llog, V, bm->k, nb / bm->k, cur_tok + r0, bscore + r0, bfin + r0, bm->path_cur + r0 * Tmax, bm->path_nxt + r0 * Tmax, Tmax,
                         bparent + r0, btok + r0, Bmax, st + li, done_flag + (size_t)li * Tmax, eos, (int)r0};
@@ -1620,8 +1639,55 @@ struct Engine : EngineBase {
         fclose(f);
     }
 
+    // txo_generate / txo_generate_from_enc.  Per-row stop (stop_mode 1, a build extension: the reference has only the global break,
+    // decoder.py:115-116): the decode below is the same loop with the same break -- rows are independent, so every row's tokens up to its first eos
+    // are what the global-break run gives -- and every token BEHIND a row's first eos becomes cfg.pad (pad_after_eos_kernel); on the launch
+    // path the finished rows also stop costing work (compact_lane).
     int generate(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
                  int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) override {
+        int steps = 0;
+        row_stop = false; last_compactions = 0;
+        const int rc = generate_impl(img, enc, B, C, H, W, N, max_len, eos, tokens_out, &steps, logits_out, s);
+        const bool compacted = last_compactions > 0;
+        row_stop = false;
+        if (rc) return rc;
+        if (n_steps) *n_steps = steps;
+        if (compacted) session = false;                           // the session's rows are no longer the batch's: a new decode must begin
+        if (stop_mode == 1 && eos >= 0 && steps > 0) {
+            hipLaunchKernelGGL(pad_after_eos_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tokens_out, max_len, steps, B, eos, cfg.bos, cfg.pad);
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipGetLastError());
+        }
+        return 0;
+    }
+    bool row_stop = false;            // this generate compacts the live rows of its row ranges (launch path, stop_mode 1)
+    // live rows of range li to its front; the range then launches `new_rows` rows (>= its live rows).  t1 = positions decoded so far.
+    int compact_lane(int li, int new_rows, int t1, int eos) {
+        Lane& ln = lanes[li];
+        hipStream_t s = ln.stream;
+        const size_t r0 = ln.b0;
+        CompactArgs ca{ln.nb, new_rows, (int)r0, cur_tok + r0, eos_seen + r0, row_map + r0, cur_tok2 + r0, row_map2 + r0, cmoves + 2 * r0,
+                       cinfo + 2 * li, st + li, eos};
+        hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, ca);
+        const int heads = cfg.dec_heads;
+        auto move = [&](void* base, size_t outer_stride, size_t inner_stride, size_t row_stride, int outer_n, int inner_n, size_t len_elems) {
+            MoveArgs ma{reinterpret_cast<unsigned char*>(base), outer_stride * sizeof(T), inner_stride * sizeof(T), row_stride * sizeof(T), inner_n,
+                        (unsigned)(len_elems * sizeof(T) / 16), cmoves + 2 * r0, cinfo + 2 * li};
+            if (ma.len16 == 0) return;
+            hipLaunchKernelGGL(move_rows_kernel, dim3((ma.len16 + 255) / 256, outer_n * inner_n), dim3(256), 0, s, ma);
+        };
+        // self-attention history [Ld][2][rows*heads][Tmax][64]: positions 0 .. t1-1 of every head of every moved row
+        move(skv + r0 * heads * Tmax * DH, (size_t)sB * Id * Tmax, (size_t)Tmax * DH, (size_t)heads * Tmax * DH, 2 * cfg.dec_layers, heads, (size_t)t1 * DH);
+        // the cross attention's operand: the session's encoder rows (latent form) or the projected K/V panels [Ld][2][rows*heads][N][64]
+        if (use_latent) move(enc_t + r0 * sN * D, 0, 0, (size_t)sN * D, 1, 1, (size_t)sN * D);
+        else move(ckv + r0 * sN * Id, (size_t)sImg * sN * Id, 0, (size_t)sN * Id, 2 * cfg.dec_layers, 1, (size_t)sN * Id);
+        ln.nb = new_rows;
+        ++last_compactions;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    int generate_impl(const float* img, const float* enc, int B, int C, int H, int W, int N, int max_len, int eos,
+                 int64_t* tokens_out, int* n_steps, float* logits_out, hipStream_t s) {
         if (max_len < 1) return fail(TXO_E_INVALID, "max_len must be >= 1");
         // max_len > decoder.max_len: the reference slides its window (decoder.py:99-100).  The first Tmax positions decode with the
         // KV cache as always (n_pos of them; rows of the outputs are max_len apart); every further token re-runs its window of the
@@ -1667,10 +1733,12 @@ struct Engine : EngineBase {
         // graph replay by default only for very small batches (B <= 4: there the host's enqueue rate bounds the step --
         // 34.2 vs 37.2 ms per generate at B = 1 -- from B = 8 on it is equal); TXO_GRAPH=1 / 0 forces it on / off
         use_latent = latent_ok && (lat_mode == 1 || (lat_mode < 0 && auto_latent(B)));
-        lat_self = use_latent && lat_self_ok();
+        // per-row stop with live-row compaction: inside the positional table, tokens only (a finished row's logits would be unspecified)
+        row_stop = stop_mode == 1 && eos >= 0 && logits_out == nullptr && max_len <= Tmax && stop_every > 0 && !prof && !prof_cross;
+        lat_self = use_latent && lat_self_ok() && !row_stop;      // (the z history is not moved by compact_lane)
         if (!use_latent) ensure_ckv(s);
         const bool want_graph = knobs.graph >= 0 ? knobs.graph != 0 : B <= 4;
-        const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph;
+        const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph || row_stop;   // (a captured step has its row count baked in)
         // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
         // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765).  Greedy and sampled alike: a draw is keyed
         // by (seed; row of the batch, position), not by the range (step.h: StepArgs::row0)
@@ -1704,6 +1772,7 @@ struct Engine : EngineBase {
         bool broke = false;                                        // the GLOBAL eos break fired inside the positional table
         look_failed = false;
         int pend_lo = -1, pend_hi = -1;                            // chunk whose flags are in flight to the host
+        int live_pend = -1;                                        // per-row stop: position behind which the ranges' finished-row counts were requested
         auto look = [&]() -> bool {                                // wait for the pending chunk's flags; true = all rows done
             for (int i = 0; i < n_lanes; ++i) HIP_TRY_B(hipEventSynchronize(ev_flags[i]));
             for (int k = pend_lo; k <= pend_hi; ++k) {
@@ -1726,6 +1795,27 @@ struct Engine : EngineBase {
                 else if (int r2 = enqueue_step(lanes[i].stream, i, tdst, tstride, logits_out, eos, nullptr, t)) return r2;
             }
             if (eos < 0) continue;
+            if (row_stop) {
+                // Live-row compaction.  The host only needs an UPPER bound of a range's live rows to size its launches, and live rows only
+                // decrease: the finished-row counter of a range is copied to pinned memory behind a step, AHEAD more steps are enqueued,
+                // and only then the host reads it (never draining the stream, like the done flags below).  compact_scan_kernel works on the
+                // state of the moment it runs; slots between its live count and the host's bound are filler rows that count as finished.
+                if (live_pend >= 0 && t == live_pend + AHEAD) {
+                    for (int i = 0; i < n_lanes; ++i) HIP_TRY(hipEventSynchronize(ev_live[i]));
+                    for (int i = 0; i < n_lanes; ++i) {
+                        const int bound = lanes[i].nb - live_host[i];
+                        if (bound >= 1 && lanes[i].nb - bound >= stop_gain) { if (int r2 = compact_lane(i, bound, t + 1, eos)) return r2; }
+                    }
+                    live_pend = -1;
+                }
+                if (live_pend < 0 && (t + 1) % stop_every == 0 && t + 1 + AHEAD < n_pos) {
+                    for (int i = 0; i < n_lanes; ++i) {
+                        HIP_TRY(hipMemcpyAsync(live_host + i, &st[i].rows_with_eos, sizeof(int), hipMemcpyDeviceToHost, lanes[i].stream));
+                        HIP_TRY(hipEventRecord(ev_live[i], lanes[i].stream));
+                    }
+                    live_pend = t;
+                }
+            }
             if (pend_lo >= 0 && (t == pend_hi + AHEAD || t + 1 == n_pos)) { if (look()) break; if (look_failed) return TXO_E_HIP; }
             if ((t + 1) % CHUNK == 0 || t + 1 == n_pos) {
                 const int lo = (t / CHUNK) * CHUNK;
@@ -1906,6 +1996,7 @@ struct Engine : EngineBase {
         else if (what == TXO_Q_LAST_ROW_RANGES) *out = last_persist ? 1 : last_ranges;
         else if (what == TXO_Q_LAST_LATENT) *out = (!last_persist && use_latent) ? 1 : 0;
         else if (what == TXO_Q_RELOAD_KNOBS) { knobs.read(); *out = 0; }
+        else if (what == TXO_Q_LAST_COMPACTIONS) *out = last_compactions;
         else return fail(TXO_E_INVALID, "unknown query");
         return 0;
     }
@@ -2047,6 +2138,12 @@ int txo_set_sampling(txo_engine* e, int32_t mode, int32_t topk, float temp, uint
     return 0;
 }
 
+int txo_set_stop_mode(txo_engine* e, int32_t mode) {
+    if (!e) return fail(TXO_E_INVALID, "null engine");
+    if (mode != TXO_STOP_GLOBAL && mode != TXO_STOP_ROW) return fail(TXO_E_INVALID, "stop mode must be TXO_STOP_GLOBAL or TXO_STOP_ROW");
+    e->impl->stop_mode = mode;
+    return 0;
+}
 int txo_profile_enable(txo_engine* e, int32_t on) { return e ? e->impl->profile_enable(on) : fail(TXO_E_INVALID, "null engine"); }
 int txo_profile_read(txo_engine* e, int32_t kind, double* avg_ms, int64_t* count) {
     return e ? e->impl->profile_read(kind, avg_ms, count) : fail(TXO_E_INVALID, "null engine");

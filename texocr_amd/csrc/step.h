@@ -31,12 +31,19 @@ struct StepArgs {
     // sampling (reference decoder.py:104-108): keep the topk largest logits, softmax(logits / temp), draw one
     int topk; float inv_temp; unsigned long long seed;
     int row0;                   // first row of this row range in the batch: a draw is keyed by (seed; row of the BATCH, t), whatever the ranges
+    // per-row stop (txo_set_stop_mode: a build extension, the reference only breaks globally): a row that already contains eos is frozen --
+    // nothing more is written for it -- and the live rows of a range may have been compacted to its front (Engine::compact_lane):
+    // row_map[row] = row of the BATCH that sits in slot `row` of the range (null: the identity).  Outputs and sampler keys follow it.
+    int stop_rows; const int* row_map;
 };
+// row of the range (relative to row0) whose outputs slot `row` produces
+__device__ inline int out_row(const StepArgs& a, int row) { return a.row_map ? a.row_map[row] - a.row0 : row; }
 
 // append the chosen token, update the GLOBAL eos bookkeeping, advance the device-side position (lane 0 of a row)
 __device__ inline void commit_token(const StepArgs& a, int row, int t, int tok) {
     a.cur_tok[row] = tok;
-    if (a.tokens_out) a.tokens_out[(size_t)row * a.out_stride + t] = tok;
+    const bool frozen = a.stop_rows && a.eos >= 0 && a.eos_seen[row];          // per-row stop: the host pads behind the row's first eos
+    if (a.tokens_out && !frozen) a.tokens_out[(size_t)out_row(a, row) * a.out_stride + t] = tok;
     unsigned add = 1u;
     if (a.eos >= 0 && tok == a.eos && !a.eos_seen[row]) { a.eos_seen[row] = 1; add += 1u << 16; }
     const unsigned old = atomicAdd(&a.st->arrive, add);
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(64) void argmax_step_kernel(StepArgs a) {
     const int t = a.st->t;
     const float* lg = a.logits + (size_t)row * a.V;
     float best = -3.4e38f; int bi = 0x7fffffff;
-    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * a.V : nullptr;
+    float* lo = a.logits_out ? a.logits_out + ((size_t)out_row(a, row) * a.out_stride + t) * a.V : nullptr;
     if ((a.V & 3) == 0) {                      // rows are 16-byte aligned: four float4 per lane in flight
         const int n4 = a.V >> 2;
         for (int base = 0; base < n4; base += 256) {
@@ -308,16 +315,102 @@ __global__ __launch_bounds__(64) void sample_step_kernel(StepArgs a) {
     const int row = blockIdx.x, lane = threadIdx.x, V = a.V;
     const int t = a.st->t;
     const float* lg = a.logits + (size_t)row * V;
-    float* lo = a.logits_out ? a.logits_out + ((size_t)row * a.out_stride + t) * V : nullptr;
+    const int orow = out_row(a, row);
+    float* lo = a.logits_out ? a.logits_out + ((size_t)orow * a.out_stride + t) * V : nullptr;
     int pick;
     if constexpr (REGS) pick = sample_row_regs([&](int j) { return lg[j]; }, [&](int j) { return ld16(lg + j); }, lo, V, lane, a.topk, a.inv_temp, a.seed,
-                                               (unsigned)(a.row0 + row), (unsigned)t);
-    else pick = sample_row_lds([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)(a.row0 + row), (unsigned)t);
+                                               (unsigned)(a.row0 + orow), (unsigned)t);
+    else pick = sample_row_lds([&](int j) { return lg[j]; }, row_lds, lo, V, lane, a.topk, a.inv_temp, a.seed, (unsigned)(a.row0 + orow), (unsigned)t);
     if (lane == 0) commit_token(a, row, t, pick);
 }
 inline void launch_sample_step(hipStream_t s, int rows, const StepArgs& sa) {
     if (sample_in_regs(sa.V)) hipLaunchKernelGGL(sample_step_kernel<true>, dim3(rows), dim3(64), 0, s, sa);
     else hipLaunchKernelGGL(sample_step_kernel<false>, dim3(rows), dim3(64), (size_t)sa.V * sizeof(float), s, sa);
+}
+
+// ---- per-row stop (a build extension; the reference breaks only globally, decoder.py:115-116) -------------------
+// Rows are independent (the only cross-row operation of the path is that global test), so a row that has produced eos needs no further
+// work: its later tokens are `pad`.  Two pieces: (1) pad_after_eos_kernel rewrites everything behind a row's first eos once the decode is
+// over (every decode path); (2) on the launch path the live rows of a row range are compacted to the front of the range every few positions
+// and the range's launches shrink -- compact_scan_kernel builds the new small state and the list of row moves, move_rows_kernel moves the
+// rows of the K/V history and of the cross-attention operand (same bits per row: nothing a row computes depends on its slot).
+__global__ void pad_after_eos_kernel(int64_t* tokens, int stride, int steps, int rows, int eos, int bos, int pad) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    int64_t* row = tokens + (size_t)r * stride;
+    bool done = bos == eos;                                   // the BOS column counts (decoder.py:115 looks at the whole output)
+    for (int t = 0; t < steps; ++t) {
+        if (done) row[t] = pad;
+        else if (row[t] == eos) done = true;
+    }
+}
+
+__global__ void iota_kernel(int* p, int n, int first) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = first + i; }
+
+struct CompactArgs {
+    int rows, new_rows, row0;             // rows of the range now / after (new_rows >= live rows: the host's bound is a few positions old)
+    int64_t* cur_tok; int* eos_seen; int* row_map;            // the range's slices, rewritten in place
+    int64_t* cur_tok2; int* row_map2;                         // scratch [rows]
+    int* moves;                           // out: (src, dst) pairs of the live rows that change slot, ascending; info = {live rows, moves}
+    int* info; StepState* st; int fill_tok;
+};
+// ONE workgroup.  Live rows keep their order, so dst <= src, and a live row moves iff a finished row precedes it: with F = the first
+// finished row (every row before it is live and stays), the live row that lands in slot dst > = F is entry dst - F of the move list.
+__global__ __launch_bounds__(1024) void compact_scan_kernel(CompactArgs a) {
+    __shared__ int wsum[16], s_base, s_first;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_base = 0; s_first = a.rows; }
+    __syncthreads();
+    for (int c0 = 0; c0 < a.rows; c0 += 1024) {
+        const int r = c0 + tid;
+        const int live = (r < a.rows && !a.eos_seen[r]) ? 1 : 0;
+        int inc = live;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (lane == 63) wsum[wave] = inc;
+        if (r < a.rows && !live) atomicMin(&s_first, r);
+        __syncthreads();
+        int before = s_base;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const int dst = before + inc - live, F = s_first;     // F is final for every row up to this chunk's end
+        if (live) {
+            a.cur_tok2[dst] = a.cur_tok[r]; a.row_map2[dst] = a.row_map[r];
+            if (dst != r) { a.moves[2 * (dst - F)] = r; a.moves[2 * (dst - F) + 1] = dst; }
+        }
+        __syncthreads();
+        if (tid == 0) { int s = s_base; for (int w = 0; w < 16; ++w) s += wsum[w]; s_base = s; }
+        __syncthreads();
+    }
+    const int L = s_base, F = min(s_first, L);
+    // slots [L, new_rows): filler rows that count as finished (the host's row count is an upper bound a few positions old)
+    for (int i = tid; i < a.new_rows; i += 1024) {
+        const bool lv = i < L;
+        a.cur_tok[i] = lv ? a.cur_tok2[i] : (int64_t)a.fill_tok;
+        a.row_map[i] = lv ? a.row_map2[i] : a.row0;
+        a.eos_seen[i] = lv ? 0 : 1;
+    }
+    if (tid == 0) { a.info[0] = L; a.info[1] = L - F; a.st->rows_with_eos = a.new_rows - L; a.st->arrive = 0u; }
+}
+
+// Moves rows of a [outer][inner_n][rows][...] family of planes: plane p = (o, i) starts at base + o * outer_stride + i * inner_stride (bytes),
+// row r of it at + r * row_stride, and the first `len16` 16-byte pieces of a row are copied from moves[2k] to moves[2k+1], k ascending.
+// A thread owns ONE piece offset of ONE plane and walks the moves in order, eight loads ahead of their stores: every store of a group goes
+// to a row <= the group's last source, and every live row up to there has been read (by this same thread, in program order) -- in place, no
+// barrier.  blockIdx.y = plane.
+struct MoveArgs { unsigned char* base; size_t outer_stride, inner_stride, row_stride; int inner_n; unsigned len16; const int* moves; const int* info; };
+__global__ __launch_bounds__(256) void move_rows_kernel(MoveArgs a) {
+    const unsigned piece = blockIdx.x * 256u + threadIdx.x;
+    if (piece >= a.len16) return;
+    const int p = blockIdx.y, o = p / a.inner_n, i = p - o * a.inner_n;
+    unsigned char* pl = a.base + (size_t)o * a.outer_stride + (size_t)i * a.inner_stride + (size_t)piece * 16;
+    const int n = a.info[1];
+    for (int k0 = 0; k0 < n; k0 += 8) {
+        u32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int k = min(k0 + u, n - 1); v[u] = ld16(pl + (size_t)a.moves[2 * k] * a.row_stride); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (k0 + u < n) st16(pl + (size_t)a.moves[2 * (k0 + u) + 1] * a.row_stride, v[u]);
+    }
 }
 
 // ---- beam search (a build extension: the reference has no beam search) -----------------------------------

@@ -198,10 +198,20 @@ class HipEngine:
         k = int((1 - threshold) * self.dims.vocab)
         _lib.check(self.lib.txo_set_sampling(self.handle, 1 if on else 0, max(k, 1), float(temp), int(seed) & (2**64 - 1)))
 
+    def set_stop_mode(self, stop: str) -> None:
+        """'global': the reference's loop (decoder.py:115-116: rows keep producing tokens after their eos, one break when every row
+        contains it).  'row' (build extension): a row is finished at its first eos -- later tokens are the pad id -- and finished rows
+        stop costing work on the launch path (txo_set_stop_mode)."""
+        if stop not in ("global", "row"):
+            raise ValueError("stop must be 'global' or 'row'")
+        self._ensure()
+        _lib.check(self.lib.txo_set_stop_mode(self.handle, 1 if stop == "row" else 0))
+
     def query(self, what: int) -> int:
         """txo_engine_query: 0 = the last generate() ran as one persistent launch, 1 = persistent launches that fell back,
         2 = row ranges (streams) of the last launch-path decode, 3 = the last decode's cross attention ran in latent form,
-        4 = (not a question) re-read the TXO_* development knobs of generate() from the environment."""
+        4 = (not a question) re-read the TXO_* development knobs of generate() from the environment, 5 = live-row compactions of the
+        last generate (stop='row' on the launch path)."""
         out = C.c_int64(0)
         _lib.check(self.lib.txo_engine_query(self.handle, int(what), C.byref(out)))
         return out.value
@@ -353,6 +363,10 @@ class AutoRegressiveDecoder(nn.Module):
         enc = kwargs.pop("enc", None)
         mask = kwargs.pop("mask", None)
         return_logits = bool(kwargs.pop("return_logits", False))   # build extension: also the logits every token was picked from
+        stop = kwargs.pop("stop", "global")                        # build extension: 'row' = per-row stop, pad behind a row's first eos
+        pad = kwargs.pop("pad", None)
+        if stop not in ("global", "row"):
+            raise ValueError("stop must be 'global' or 'row'")
         if kwargs:
             raise ValueError(f"unsupported arguments: {sorted(kwargs)}")
         if enc is None:
@@ -374,6 +388,8 @@ class AutoRegressiveDecoder(nn.Module):
                 seed = generator.initial_seed() if generator is not None else int(torch.randint(0, 2**62, (1,)).item())
             eng.set_sampling(True, temp=temp, seed=seed)
             self._resample = (temp, seed)
+        if stop == "row":
+            eng.set_stop_mode("row")
         try:
             # beyond the positional table the engine slides the window with its multi-position forward, which needs a vocabulary
             # that is a multiple of 8 and a table that fits its workspace -- else the general stepwise loop below
@@ -391,6 +407,12 @@ class AutoRegressiveDecoder(nn.Module):
         finally:
             if decode == "sample":
                 eng.set_sampling(False)
+            if stop == "row":
+                eng.set_stop_mode("global")
+        if stop == "row" and eos_tok is not None and not return_logits:
+            # (the engine's own generate has padded already; the stepwise loop -- arbitrary start prefix, padding mask -- is padded here:
+            # the same rule, tokens behind a row's first eos, start tokens included in the test as decoder.py:115 does)
+            out = _pad_after_eos(out, st.to(out.device), eos_tok, eng.dims.pad if pad is None else int(pad))
         if return_logits:
             return (out[0].squeeze(0), out[1].squeeze(0)) if squeeze else out
         return out.squeeze(0) if squeeze else out
@@ -441,6 +463,16 @@ class AutoRegressiveDecoder(nn.Module):
         if m is not None:
             eng.set_key_mask(None)
         return output[:, T0:]
+
+
+def _pad_after_eos(tokens: torch.Tensor, start: torch.Tensor, eos: int, pad: int) -> torch.Tensor:
+    """stop='row': every token behind a row's first eos (looked for in start tokens + output, decoder.py:115) becomes `pad`."""
+    if tokens.numel() == 0:
+        return tokens
+    seen_before = (start == eos).any(dim=1, keepdim=True)
+    is_eos = tokens == eos
+    prior = (torch.cumsum(is_eos.to(torch.int32), dim=1) - is_eos.to(torch.int32)) > 0     # an eos strictly before this column
+    return torch.where(prior | seen_before, torch.full_like(tokens, pad), tokens)
 
 
 class OCRModel(nn.Module):
@@ -497,18 +529,27 @@ class OCRModel(nn.Module):
     @torch.no_grad()
     def generate(self, src: torch.Tensor, max_len: int, temp: float = 0.3, *, decode: str = "greedy",
                  generator: Optional[torch.Generator] = None, seed: Optional[int] = None, return_logits: bool = False,
-                 beam: int = 0, return_beams: bool = False):
+                 beam: int = 0, return_beams: bool = False, stop: str = "global"):
+        if stop not in ("global", "row"):
+            raise ValueError("stop must be 'global' or 'row'")
         if beam:                                           # build extension (BASELINE config 5); engine max_batch >= B * beam
             if max_len > self.decoder.max_len:
                 raise ValueError(f"beam search needs max_len <= decoder.max_len ({self.decoder.max_len})")
             return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
         if decode == "greedy" and self.bos_token == self._engine.dims.bos:
             # (max_len > decoder.max_len: txo_generate slides the window like the reference, decoder.py:99-100)
+            if stop == "row" and not return_logits:
+                self._engine.set_stop_mode("row")
+                try:
+                    return self._engine.generate(src, max_len, self.eos_token)
+                finally:
+                    self._engine.set_stop_mode("global")
             return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
         enc = self.encoder(src)
         start = torch.full((src.shape[0], 1), self.bos_token, dtype=torch.int64, device=src.device)   # ocr_model.py:57
         return self.decoder.generate(start_tokens=start, eos_tok=self.eos_token, max_len=max_len, temp=temp,
-                                     decode=decode, generator=generator, seed=seed, enc=enc, return_logits=return_logits)
+                                     decode=decode, generator=generator, seed=seed, enc=enc, return_logits=return_logits,
+                                     stop=stop, pad=self.trg_pad_idx)
 
     def forward(self, *a, **k):
         raise NotImplementedError("OCRModel.forward is the training loss (ocr_model.py:38-44); this engine "
