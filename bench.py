@@ -15,7 +15,7 @@ Objects on the line besides the contract's fields:
                   script (live_pmc; N=1 default run) or, failing that, from the tracked profiles/ file -- `traffic_source` says which.
   cpu_baseline -- the oracle (oracle/cpu_ref.py, "port") on this host: `value` = recompute mode = the reference's
                   algorithm (no KV cache, decoder.py:97-103) on a bounded sample; `cached` = the same oracle with a KV cache.
-  fp32_parity_mode, sampled_decode, b256, cfg4, cfg5_beam (N=1 only, after the timed region; --no-extras skips them):
+  fp32_parity_mode, sampled_decode, b256, cfg4, cfg5_beam, row_stop_b256 (N=1 only, after the timed region; --no-extras skips them):
                   the token-exact fp32 engine on the same workload; the reference's default (sampled) decode; batch 256 (the north-star HBM target: cross-attention
                   >= 50 % of 8 TB/s); BASELINE configs[3] (ViT-Base 12L/768d + 6L decoder, B=256: encoder >= 40 % of the
                   bf16 MFMA peak).
@@ -277,6 +277,61 @@ def beam_measurement(dtype, a, dev, B=128, k=5, widths=(224, 448, 672, 896)):
     del m
     torch.cuda.empty_cache()
     return out
+
+
+def row_stop_measurement(dims, dtype, a, dev, B=256, target_median=90):
+    """Per-row eos stop (stop='row', a build extension: SURVEY D7 / 8f N2) against the reference's global break on a SYNTHETIC eos
+    schedule: random-init weights never produce eos, so to_logits.bias[eos] is raised until the median row finishes after about
+    `target_median` tokens (bisection on the device; the schedule that results is reported).  Both runs decode the same rows to the
+    same tokens up to each row's first eos (tests/test_gpu_stop.py); the global-break run keeps every row in every launch until the
+    LAST row has finished, the row-stop run compacts the live rows of its row ranges every 16 positions."""
+    import numpy as np
+    import torch
+    from texocr_amd import synth
+    from texocr_amd.model import model_from_dims
+    N = dims.n_tokens(a.height, a.width)
+    m = model_from_dims(dims, dtype=dtype, max_batch=B, max_tokens=N)
+    sd = synth.synth_state_dict(dims, 0)
+    base = sd["decoder.net.to_logits.bias"].copy()
+    g = torch.Generator(device=dev).manual_seed(777)
+    img = torch.rand((B, dims.in_channels, a.height, a.width), generator=g, device=dev, dtype=torch.float32)
+    img = img * torch.linspace(0.4, 1.6, B, device=dev)[:, None, None, None]          # rows differ: their eos positions spread
+
+    def first_eos(bias):
+        b = base.copy(); b[dims.eos] += bias
+        sd["decoder.net.to_logits.bias"] = b
+        m.load_state_dict(sd)
+        t = m.generate(img, a.max_len).cpu().numpy()
+        f = np.array([(np.nonzero(r == dims.eos)[0][0] + 1) if (r == dims.eos).any() else a.max_len + 1 for r in t])
+        return f, t.shape[1]
+    lo, hi = 0.0, 12.0
+    for _ in range(10):
+        mid = 0.5 * (lo + hi)
+        f, _ = first_eos(mid)
+        if np.median(f) > target_median: lo = mid
+        else: hi = mid
+    f, n_steps = first_eos(hi)
+
+    def run(**kw):
+        for _ in range(2): m.generate(img, a.max_len, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): out = m.generate(img, a.max_len, **kw)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / 5, out
+    sec_g, out_g = run()
+    sec_r, out_r = run(stop="row")
+    comp = m._engine.query(5)
+    same = bool(((out_g == out_r) | (out_r == dims.pad)).all().item()) and out_g.shape == out_r.shape
+    res = {"batch": B, "dtype": dtype, "max_len": a.max_len, "eos_bias": round(hi, 3), "steps_decoded": int(n_steps),
+           "row_lengths": {"median": float(np.median(f)), "mean": round(float(f.mean()), 1), "p90": float(np.percentile(f, 90)), "max": int(f.max()),
+                           "rows_without_eos": int((f > a.max_len).sum())},
+           "global_break": {"value": round(B / sec_g, 1), "unit": "images/sec", "ms_per_step": round(1000 * sec_g, 3)},
+           "row_stop": {"value": round(B / sec_r, 1), "unit": "images/sec", "ms_per_step": round(1000 * sec_r, 3), "compactions": int(comp)},
+           "speedup": round(sec_g / sec_r, 3), "tokens_agree_up_to_each_rows_eos": same,
+           "note": "synthetic eos schedule (bias on the eos logit, random-init weights); global_break = the reference's loop (decoder.py:115-116)"}
+    del m
+    torch.cuda.empty_cache()
+    return res
 
 
 def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encoder, sampled=False):
@@ -551,6 +606,8 @@ def main():
                 result["cfg4"] = side_measurement(d4, a.dtype, 256, a, dev, 1, 3, True, True)
                 result["cfg4"]["workload"] = "BASELINE configs[3]: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h), batch 256"
                 result["cfg5_beam"] = beam_measurement(a.dtype, a, dev)
+                result["cfg5_beam"]["parity"] = "unpinned beyond k=1: the reference has no beam search (checked against the oracle's own beam search only)"
+                result["row_stop_b256"] = row_stop_measurement(dims, a.dtype, a, dev)
             except Exception as e:                          # a side measurement must never lose the headline line
                 result["extras_error"] = f"{type(e).__name__}: {e}"
         if not a.no_cpu_baseline and world == 1:            # reported at N=1 only (bench contract)
