@@ -369,6 +369,30 @@ def cap_hybrid():
 
 
 @torch.no_grad()
+def cap_hybrid_full():
+    """N1 at the default factory's REAL size (VERDICT r05 missing 3): create_model(config/config.yml) on its full 1x160x1008 canvas
+    (encoder.py:172-191: 10 x 63 patches + CLS = 631 tokens), two images, 32 greedy steps from the reference; encoder output in full."""
+    cfg = reference_config()
+    cfg["device"] = "cpu"
+    d = Dims.from_config(cfg)
+    seed, img_seed = 5, 78
+    model = ref_create_model({k: v for k, v in cfg.items() if k not in ("embed",)}).eval()
+    sd_np = synth.synth_state_dict(d, seed)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()})
+    img = torch.from_numpy(synth.synth_images(2, 1, 160, 1008, img_seed))
+    emb = model.encoder.patch_embed(img)
+    enc = model.encoder(img)
+    with greedy_patch() as gp:
+        toks = model.generate(img, max_len=32)
+    step_logits = torch.stack(gp.logits, 1)
+    save("hybrid_b2_160x1008", {"dims": d.to_dict(), "weight_seed": seed, "image_seed": img_seed, "image_shape": [2, 1, 160, 1008],
+                                "max_len": 32, "tokens_per_image": int(enc.shape[1]),
+                                "note": "embed_every8 = every 8th patch row of HybridEmbedding's output (backbone + 1x1 projection)"},
+         embed_every8=emb.numpy()[:, ::8].astype(np.float32), enc=enc.numpy(), tokens=toks.numpy().astype(np.int16),
+         step_logits=step_logits.numpy(), margin=margins(step_logits))
+
+
+@torch.no_grad()
 def cap_cfg4():
     """G10 / BASELINE config 4: ViT-Base encoder (12L/768d/12h) + 6-layer decoder (768d/12h: encoder and decoder widths
     must match), 3x224x672 (N=589), B=2, 8 greedy steps from the reference (encoder.py:75-121, decoder.py:148-173)."""
@@ -519,7 +543,7 @@ def cap_tokenizer():
     print("[golden] tokenizer_cases.json", len(cases), "cases")
 
 
-CAPS = {"ragged": cap_ragged, "cfg2_full": cap_cfg2_full, "cfg4_t64": cap_cfg4_t64, "tokenizer": cap_tokenizer, "cfg4": cap_cfg4, "wrapper": cap_wrapper, "hybrid": cap_hybrid, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
+CAPS = {"ragged": cap_ragged, "cfg2_full": cap_cfg2_full, "cfg4_t64": cap_cfg4_t64, "tokenizer": cap_tokenizer, "cfg4": cap_cfg4, "wrapper": cap_wrapper, "hybrid": cap_hybrid, "hybrid_full": cap_hybrid_full, "tiny": cap_tiny, "cfg1": cap_cfg1, "cfg2": cap_cfg2, "posids": cap_posids, "eos": cap_eos,
         "window": cap_window, "sampling": cap_sampling}
 
 if __name__ == "__main__":
