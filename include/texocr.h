@@ -64,11 +64,15 @@ void txo_engine_destroy(txo_engine* e);
 /* nn.Module.load_state_dict, one tensor at a time (key layout of OCRModel.state_dict()):
  * `key` is the reference state_dict key, `data` HOST float32, `shape`/`ndim` its shape.  Aliased shared
  * LayerNorm keys (layers.{s}.0.weight for every s, attention.py:200,221) may all be passed; they must
- * carry identical values.  txo_engine_finalize_weights checks completeness and uploads. */
+ * carry identical values.  txo_engine_finalize_weights checks completeness, refuses non-finite values (TXO_E_INVALID, the key is
+ * named in txo_last_error) and uploads. */
 int txo_engine_set_weight(txo_engine* e, const char* key, const float* data, const int64_t* shape, int32_t ndim);
 int txo_engine_finalize_weights(txo_engine* e);
 
-/* VisionEncoder.forward (encoder.py:128-152): img_dev [B,C,H,W] -> enc_out_dev [B, 1+(H/16)(W/16), D]. */
+/* VisionEncoder.forward (encoder.py:128-152): img_dev [B,C,H,W] -> enc_out_dev [B, 1+(H/16)(W/16), D].
+ * Non-finite input: weights are checked (txo_engine_finalize_weights refuses NaN / inf); pixels are not.  A non-finite pixel makes the
+ * rows of ITS OWN image unspecified -- encoder rows, logits, and token ids that are unspecified but always inside the vocabulary (the
+ * reference would return NaN logits and argmax's pick among them) -- and touches no other image of the batch: rows never interact. */
 int txo_encode(txo_engine* e, const float* img_dev, int32_t B, int32_t C, int32_t H, int32_t W,
                float* enc_out_dev, void* stream);
 
@@ -80,7 +84,8 @@ int txo_decode_begin(txo_engine* e, const float* enc_dev, int32_t B, int32_t N, 
 /* One position of Transformer.forward in KV-cached form (decoder.py:41-67): feeds tok_in_dev[B] (NULL =
  * the engine's current token: bos, or the previous step's argmax) at position t (t must equal the number
  * of positions decoded since txo_decode_begin, or less to rewind), writes the position's logits
- * [B,vocab] to logits_out_dev (may be NULL) and their argmax to tok_out_dev[B] (may be NULL). */
+ * [B,vocab] to logits_out_dev (may be NULL) and their argmax to tok_out_dev[B] (may be NULL).  Token ids outside [0, vocab) are
+ * forced into the table (the reference's nn.Embedding raises IndexError; the Python facade checks and raises too). */
 int txo_decode_step(txo_engine* e, const int64_t* tok_in_dev, int32_t t, float* logits_out_dev,
                     int64_t* tok_out_dev, void* stream);
 

@@ -580,22 +580,97 @@ def test_sampling_mode_support_reproducibility_and_distribution():
     assert chi < dof + 6 * (2 * dof) ** 0.5, (chi, dof)             # ~6 sigma of the chi-square law
 
 
-def test_world1_rccl_allgather_smoke():
+def test_non_finite_input_policy():
+    """Weights: NaN / inf refused when they are uploaded (TXO_E_INVALID naming the key).  Pixels: a NaN pixel makes the rows of its own image
+    unspecified -- token ids still inside the vocabulary, no fault -- and changes nothing for the other images of the batch (rows never
+    interact; the reference would return NaN logits for that image).  Token ids outside the vocabulary: IndexError like nn.Embedding."""
+    d = Dims(canvas=224)
+    sd = synth.synth_state_dict(d, 0)
+    for dtype, B in (("fp32", 4), ("bf16", 4), ("bf16", 130)):           # persistent launch (fp32, bf16) and the launch path (130 rows)
+        _, _, m = build(d, sd=sd, dtype=dtype, max_batch=B)
+        img = torch.rand((B, 3, 64, 128), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        clean = m.generate(img, 24).cpu()
+        bad = img.clone()
+        bad[1, 0, 5, 7] = float("nan")
+        bad[2, 1, 9, 3] = float("inf")
+        for kw in ({}, {"decode": "sample", "seed": 5, "temp": 0.7}, {"beam": 2} if B * 2 <= 8 else {}):
+            if kw.get("beam"):
+                _, _, mb = build(d, sd=sd, dtype=dtype, max_batch=B * 2)
+                ref, got = mb.generate(img, 24, **kw).cpu(), mb.generate(bad, 24, **kw).cpu()
+            else:
+                ref, got = (clean if not kw else m.generate(img, 24, **kw).cpu()), m.generate(bad, 24, **kw).cpu()
+            assert got.shape[0] == B and int(got.min()) >= 0 and int(got.max()) < d.vocab, (dtype, B, kw)
+            keep = [i for i in range(B) if i not in (1, 2)]
+            n = min(ref.shape[1], got.shape[1])
+            assert torch.equal(got[keep, :n], ref[keep, :n]), (dtype, B, kw)
+        assert torch.isfinite(m.encoder(bad)[keep]).all()
+    bad_sd = dict(sd)
+    w = sd["decoder.net.to_logits.weight"].copy()
+    w[3, 4] = np.nan
+    bad_sd["decoder.net.to_logits.weight"] = w
+    with pytest.raises(ValueError, match="non-finite value in weight decoder.net.to_logits.weight"):
+        build(d, sd=bad_sd)[2].generate(torch.rand(1, 3, 32, 32, device="cuda"), 2)
+    _, _, m = build(d, sd=sd, max_batch=2)
+    enc = m.encoder(torch.rand(2, 3, 32, 32, device="cuda"))
+    with pytest.raises(IndexError):
+        m.decoder.net(torch.tensor([[d.bos, d.vocab]] * 2, device="cuda"), enc=enc)
+    with pytest.raises(IndexError):
+        m.decoder.generate(torch.tensor([[-1]] * 2, device="cuda"), d.eos, 4, enc=enc)
+    # straight through the C ABI an id outside the table is forced into it (no fault, finite logits)
+    m._engine.decode_begin(enc)
+    lg, _ = m._engine.decode_step(0, torch.tensor([d.vocab + 5, -7], device="cuda"))
+    assert torch.isfinite(lg).all()
+
+
+def test_world1_rccl_collectives_really_run():
+    """One-rank "nccl" (= RCCL) group on the one GPU a test box has: every collective of texocr_amd/dist.py is ISSUED (force_collective) and
+    checked to have gone through torch.distributed.all_gather_into_tensor with an output buffer that is not its input -- the token
+    gather, the logits gather north_star names, and the bucketed beam-search gather of BASELINE configs[4].  No 1 -> 8 GPU curve exists
+    for this repository (no multi-GPU hardware in the pool): world sizes > 1 are covered by the gloo tests in tests/test_host_cpu.py."""
     import os
     import torch.distributed as dist
-    from texocr_amd.dist import sharded_generate
+    from texocr_amd import dist as tdist
+    from texocr_amd.dist import sharded_generate, sharded_generate_bucketed
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29611")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = []
+    real = dist.all_gather_into_tensor
+
+    def spy(out, inp, group=None, async_op=False):
+        calls.append((out.data_ptr(), inp.data_ptr(), tuple(out.shape), tuple(inp.shape), out.dtype))
+        return real(out, inp, group=group, async_op=async_op)
+    tdist.dist.all_gather_into_tensor = spy
     try:
+        assert dist.get_backend() == "nccl"
         d = Dims(canvas=64, embed_dim=64, enc_heads=1, enc_layers=1, dec_heads=1, dec_layers=1, vocab=32, max_len=8,
                  bos=30, eos=29, pad=31)
-        d, sd, m = build(d, seed=1, max_batch=4)
+        d, sd, m = build(d, seed=1, max_batch=20)
         img = torch.rand(4, 3, 32, 32, device="cuda")
-        want = m.generate(img, 8)
-        got = sharded_generate(lambda x, n: m._engine.generate(x, n, None), img, 8, eos=d.eos, bos=d.bos)
+        want, want_lg = m._engine.generate(img, 8, d.eos, return_logits=True)
+        # 1. token ids
+        got = sharded_generate(lambda x, n: m._engine.generate(x, n, None), img, 8, eos=d.eos, bos=d.bos, force_collective=True)
         assert torch.equal(got, want)
+        assert len(calls) == 1 and calls[0][0] != calls[0][1] and calls[0][2] == (4, 8) and calls[0][4] == torch.int64
+        # 2. tokens + per-step logits (north_star: "all-gather of logits")
+        got, lg = sharded_generate(lambda x, n: m._engine.generate(x, n, None, return_logits=True), img, 8, eos=d.eos, bos=d.bos,
+                                   gather_logits=True, force_collective=True)
+        assert torch.equal(got, want) and torch.equal(lg, want_lg[:, :got.shape[1]])
+        assert len(calls) == 3 and calls[2][2] == (4, 8, d.vocab) and calls[2][4] == torch.float32 and calls[2][0] != calls[2][1]
+        # 3. bucketed widths, greedy and beam search (BASELINE configs[4]): one gather for all buckets
+        imgs = [torch.rand(3, 32, w, device="cuda") for w in (32, 48, 32, 64, 48, 32)]
+        ref_rows = tdist.generate_bucketed(lambda x: m.generate(x, 8), imgs, max_batch=4)
+        rows = sharded_generate_bucketed(lambda x, n: m._engine.generate(x, n, None), imgs, 8, eos=d.eos, bos=d.bos, max_batch=4,
+                                         force_collective=True)
+        assert len(calls) == 4 and calls[3][0] != calls[3][1]
+        assert all(torch.equal(a, b) for a, b in zip(rows, ref_rows))
+        beam_ref = tdist.generate_bucketed(lambda x: m.generate(x, 8, beam=3), imgs, max_batch=4)
+        beam_rows = sharded_generate_bucketed(lambda x, n: m.generate(x, n, beam=3), imgs, 8, eos=d.eos, bos=d.bos, max_batch=4, beam=True,
+                                              force_collective=True)
+        assert len(calls) == 5 and calls[4][0] != calls[4][1]
+        assert all(torch.equal(a, b) for a, b in zip(beam_rows, beam_ref))
     finally:
+        tdist.dist.all_gather_into_tensor = real
         dist.destroy_process_group()
 
 

@@ -506,6 +506,11 @@ struct Engine : EngineBase {
     int finalize() override {
         if (ready) return fail(TXO_E_STATE, "weights already finalized");
         const txo_config& c = cfg;
+        // non-finite weights are refused: the library is built with -fno-honor-nans (build.py), and a NaN / inf in a weight would reach
+        // every row of every batch.  (Non-finite PIXELS reach only their own image's rows: txo_encode's contract.)
+        for (auto& kv : host)
+            for (float v : kv.second.data)
+                if (!std::isfinite(v)) return fail(TXO_E_INVALID, "non-finite value in weight " + kv.first);
         {   // weights arena: fp32 size of everything handed in is an upper bound for both storage types
             size_t bytes = 0;
             for (auto& kv : host) bytes += kv.second.data.size() * sizeof(float) + 512;
@@ -1408,7 +1413,7 @@ struct Engine : EngineBase {
                                        "window, decoder.py:99-100; a KV cache cannot reproduce that)");
         if (n_lanes != 1) return fail(TXO_E_STATE, "decode_step needs a session started by txo_decode_begin");
         lanes[0].stream = s;
-        if (tok_in) HIP_TRY(hipMemcpyAsync(cur_tok, tok_in, sizeof(int64_t) * sB, hipMemcpyDeviceToDevice, s));
+        if (tok_in) hipLaunchKernelGGL(copy_tokens_kernel, dim3((sB + 255) / 256), dim3(256), 0, s, cur_tok, tok_in, sB, V);
         hipLaunchKernelGGL(set_position_kernel, dim3(1), dim3(1), 0, s, st, t);
         if (int r = enqueue_step(s, 0, nullptr, 0, nullptr, -1, nullptr, t)) return r;
         if (logits_out) HIP_TRY(hipMemcpyAsync(logits_out, dlogits, sizeof(float) * sB * V, hipMemcpyDeviceToDevice, s));

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(PS_THREADS) void decode_persist_kernel(PersistArgs<
                 wave_argmax(best, bi);                                        // ties -> lowest index (torch.argmax)
                 }
                 if (lane == 0) {
+                    bi = in_vocab(bi, a.V);                                       // (non-finite logits: step.h)
                     a.cur_tok[row] = bi;
                     a.tokens_out[(size_t)row * a.out_stride + t] = bi;
                     if (a.eos >= 0 && bi == a.eos &&

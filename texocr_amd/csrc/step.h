@@ -40,7 +40,11 @@ struct StepArgs {
 __device__ inline int out_row(const StepArgs& a, int row) { return a.row_map ? a.row_map[row] - a.row0 : row; }
 
 // append the chosen token, update the GLOBAL eos bookkeeping, advance the device-side position (lane 0 of a row)
+// a token id a selection can produce only from non-finite logits (arg-max over NaNs finds nothing: index 0x7fffffff) must never reach
+// the next position's embedding lookup: ids are forced into the vocabulary (txo_encode: non-finite input gives unspecified, in-range tokens)
+__device__ inline int in_vocab(int tok, int V) { return (unsigned)tok < (unsigned)V ? tok : 0; }
 __device__ inline void commit_token(const StepArgs& a, int row, int t, int tok) {
+    tok = in_vocab(tok, a.V);
     a.cur_tok[row] = tok;
     const bool frozen = a.stop_rows && a.eos >= 0 && a.eos_seen[row];          // per-row stop: the host pads behind the row's first eos
     if (a.tokens_out && !frozen) a.tokens_out[(size_t)out_row(a, row) * a.out_stride + t] = tok;
@@ -345,6 +349,11 @@ __global__ void pad_after_eos_kernel(int64_t* tokens, int stride, int steps, int
     }
 }
 
+// txo_decode_step's tok_in: ids outside [0, vocab) are forced into the table (the reference's nn.Embedding would raise; the Python facade does)
+__global__ void copy_tokens_kernel(int64_t* dst, const int64_t* src, int n, int V) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const long long v = src[i]; dst[i] = v < 0 ? 0 : (v >= V ? V - 1 : v); }
+}
 __global__ void iota_kernel(int* p, int n, int first) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = first + i; }
 
 struct CompactArgs {
@@ -511,7 +520,8 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
         int allfin = 1;
 #pragma unroll
         for (int r = 0; r < KMAX; ++r) if (r < k) {
-            const int j = si[r] / V, v = si[r] - j * V;
+            const int sel = (unsigned)si[r] < (unsigned)(k * V) ? si[r] : 0;         // (non-finite logits select nothing: stay inside the image's candidates)
+            const int j = sel / V, v = sel - j * V;
             int fj = 0;
 #pragma unroll
             for (int q = 0; q < KMAX; ++q) if (q == j) fj = fn[q];
@@ -583,7 +593,8 @@ __global__ __launch_bounds__(256) void beam_select_kernel(BeamArgs a) {
     // new beams: slot r of this image continues beam seli[r] / V with token seli[r] % V
     int allfin = 1;
     for (int r = 0; r < k; ++r) {
-        const int j = seli[r] / V, v = seli[r] - j * V;
+        const int sel = (unsigned)seli[r] < (unsigned)(k * V) ? seli[r] : 0;         // (non-finite logits: see above)
+        const int j = sel / V, v = sel - j * V;
         const int nf = s_fin[j] | ((a.eos >= 0 && v == a.eos) ? 1 : 0);
         allfin &= nf;
         if (tid == r) {

@@ -137,7 +137,7 @@ def bucket_plan(images, global_batch: int) -> List[List[int]]:
 
 def sharded_generate_bucketed(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images, max_len: int,
                               eos: Optional[int], bos: Optional[int] = None, group=None, max_batch: int = 64,
-                              beam: bool = False):
+                              beam: bool = False, force_collective: bool = False):
     """BASELINE config 5 across the ranks of one node: variable-width images are bucketed by exact size, every batch of a
     bucket is sharded ACROSS the ranks (so all ranks run the same shapes at the same time), each rank decodes its shard
     (greedy, or beam search whose beams stay on their image's rank), and ONE all-gather returns every batch's token rows
@@ -149,7 +149,8 @@ def sharded_generate_bucketed(generate_local: Callable[[torch.Tensor, int], torc
       beam=True: the engine's beam search with its eos handling on (n <= max_len: the local loop stops when every beam of
         every LOCAL image is finished; a finished beam only repeats eos, at no cost, so rows are padded with eos up to the
         batch's longest shard -- what an unsharded run of the whole batch returns).
-    `images` is the GLOBAL list (every rank holds it, or at least the images of its own shards)."""
+    `images` is the GLOBAL list (every rank holds it, or at least the images of its own shards).
+    force_collective: issue the all-gather even in a one-rank group (tests / bench on one GPU exercise the RCCL call itself)."""
     if beam and eos is None:
         raise ValueError("beam search needs an eos token")
     ready = dist.is_initialized()
@@ -171,7 +172,7 @@ def sharded_generate_bucketed(generate_local: Callable[[torch.Tensor, int], torc
         blocks.append(block)
         talls.append(tall)
     local = torch.cat(blocks, dim=0)
-    if world > 1:
+    if world > 1 or (force_collective and ready):                     # (force_collective: the RCCL call itself also in a one-rank group)
         full = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
         dist.all_gather_into_tensor(full, local.contiguous(), group=group)
         full = full.view(world, local.shape[0], max_len + 1)

@@ -292,6 +292,13 @@ class VisionEncoder(nn.Module):
         return self._engine.encode(x)
 
 
+def _check_token_ids(tokens: torch.Tensor, vocab: int) -> None:
+    """The reference's nn.Embedding raises IndexError for an id outside the table (decoder.py:51); so does this facade (the C ABI
+    forces such ids into the table instead: it cannot raise from the device)."""
+    if tokens.numel() and (int(tokens.min()) < 0 or int(tokens.max()) >= vocab):
+        raise IndexError(f"token id outside the vocabulary [0, {vocab})")
+
+
 class Transformer(nn.Module):
     """model.decoder.net: (B,t) int64 tokens -> (B,t,V) logits over the whole prefix (decoder.py:41-67): ONE causal
     multi-position pass (txo_decode_prefill), which also leaves the K/V cache filled for the positions given."""
@@ -315,6 +322,7 @@ class Transformer(nn.Module):
         if x.shape[1] > self.max_len:
             raise ValueError("prefix longer than decoder.max_len")
         eng = self._engine
+        _check_token_ids(x, eng.dims.vocab)
         eng.decode_begin(enc)
         one_pass = eng.dims.vocab % 8 == 0 and x.shape[1] <= eng.max_batch * eng.max_tokens and os.environ.get("TXO_NET_STEPWISE") is None
         if padded:
@@ -382,6 +390,7 @@ class AutoRegressiveDecoder(nn.Module):
         st = start_tokens[None, :] if squeeze else start_tokens                  # decoder.py:88
         B, T0 = st.shape
         eng = self._engine
+        _check_token_ids(st, eng.dims.vocab)
         self._resample = None
         if decode == "sample":
             if seed is None:
