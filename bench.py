@@ -88,8 +88,19 @@ def live_pmc(a):
                     raise TimeoutError
                 d = os.path.join(tmp, kind, counter)
                 env = dict(os.environ, TMPDIR="/tmp", **env_extra)
-                subprocess.run([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + base + args,
-                               env=env, cwd=ROOT, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+                # own session: a timeout must end the profiler AND the python child it started (a survivor would decode beside the timed region)
+                pr = subprocess.Popen([exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--"] + base + args,
+                                      env=env, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    pr.wait(timeout=240)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    try:
+                        os.killpg(pr.pid, signal.SIGKILL)
+                    except OSError:
+                        pass
+                    pr.wait()
+                    raise
                 got = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for r in csv.DictReader(open(f)):
@@ -101,8 +112,8 @@ def live_pmc(a):
             LIVE_PMC[kind] = {"traffic_bytes": int(2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024),
                               "source": "measured in this run: two rocprofv3 --pmc child passes of this script (FETCH_SIZE, WRITE_SIZE; "
                                         "--kernel-trace only), read bytes = 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, average over the pass's launches"}
-    except Exception:
-        pass
+    except Exception as e:                                  # the line then quotes the tracked profiles/ file -- and says why
+        LIVE_PMC["error"] = f"{type(e).__name__}: {e}"[:200]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -664,6 +675,8 @@ def main():
             else:
                 cross.update(enc)
                 result["roofline"] = cross
+        if "error" in LIVE_PMC:
+            result["live_pmc_error"] = LIVE_PMC["error"]
         if world == 1 and not a.no_extras:
             del model, eng
             torch.cuda.empty_cache()

@@ -208,11 +208,8 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const float* __restrict__
 //   S^T = K Q^T : A = K rows from LDS (128-byte rows, XOR-swizzled), B = Q fragments in registers (pre-scaled).
 //   P   -> bf16 : the S^T accumulators of two 16-key tiles, converted and packed, ARE the B operand of one 32-key
 //                 k-step of O^T += V^T P^T (k-slot j of lane group g = key 4g+j of the first tile for j < 4,
-//                 key 16+4g+(j-4) of the second) -- still no LDS round trip for P.
-//   V^T         : V is transposed on its way into LDS (Vt[d][key], 136-byte rows) so that the A operand of that
-//                 k-step is two 8-byte reads per lane (keys 4g..4g+3 and 16+4g..16+4g+3 of row d).
-// q,k,v: bf16 head-major [B*heads][N][64].  Bound: MFMA bf16 (2.5 PF peak), in practice softmax VALU ~ MFMA time.
-constexpr int EAB_VT_STRIDE = 136;   // bytes per Vt row: 64 keys * 2 B + 8 pad (ds_read_b64 conflict-free across 16 rows)
+//                 key 16+4g+(j-4) of the second) -- no LDS round trip for P.
+// (The first form of it, with V transposed by 2-byte scatters on its way into LDS, was removed in r06: git history, r01-r05.)
 
 // two f32 -> packed bf16 pair (lo = a, hi = b) in one v_cvt_pk_bf16_f32
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -224,189 +221,6 @@ __device__ inline unsigned pack_bf16x2(float a, float b) {
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float EAB_GROW = 6.0f;      // base-2 units: P stays below 64 between shifts (bf16 / f32 keep their relative precision)
 
-template <typename TO>
-__global__ __launch_bounds__(256) void enc_attn_bf16_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ Kg,
-                                                            const bf16* __restrict__ Vg, TO* __restrict__ out, int N, int heads, int nbh) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2][EA_KSTAGE * 128 + DH * EAB_VT_STRIDE];   // [buf]{K | Vt}
-    static_assert(2 * (EA_KSTAGE * 128 + DH * EAB_VT_STRIDE) >= 4 * 32 * 64 * 4, "epilogue tile must fit");
-    int bh, qblk;
-    if (!ea_block((N + EA_QBLK - 1) / EA_QBLK, nbh, bh, qblk)) return;
-    const int b = bh / heads, head = bh - b * heads;
-    const int q0 = qblk * EA_QBLK;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lc = lane & 15, lg = lane >> 4;
-    const bf16* Qb = Q + (size_t)bh * N * DH;
-    const bf16* Kb = Kg + (size_t)bh * N * DH;
-    const bf16* Vb = Vg + (size_t)bh * N * DH;
-
-    // Q fragments: lane (query lc, group lg) holds Q[query][32ks + 8lg .. +7], pre-scaled by 0.125 * log2(e): the scores come
-    // out in base-2 units, so the softmax needs one v_exp_f32 per score and no multiply
-    u32x4 qf[2][2];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const int qrow = min(q0 + wave * 32 + qt * 16 + lc, N - 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const u32x4 raw = ld16(Qb + (size_t)qrow * DH + ks * 32 + lg * 8);
-            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-            unsigned o[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                union { bf16 h[2]; unsigned u; } c;
-                c.h[0] = __float2bfloat16(__uint_as_float(w[k] << 16) * (ATTN_SCALE * LOG2E));
-                c.h[1] = __float2bfloat16(__uint_as_float(w[k] & 0xffff0000u) * (ATTN_SCALE * LOG2E));
-                o[k] = c.u;
-            }
-            qf[qt][ks] = u32x4{o[0], o[1], o[2], o[3]};
-        }
-    }
-
-    f32x4 o[2][4];
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-1e30f, -1e30f}, l_run[2] = {0.f, 0.f};
-
-    // staging: 64 keys x 128 B = 512 16-byte pieces per operand, 2 per thread
-    u32x4 rk[2], rv[2];
-    auto load_stage = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
-            const int key = min(s * EA_KSTAGE + row, N - 1);
-            rk[i] = ld16(Kb + (size_t)key * DH + piece * 8);
-            rv[i] = ld16(Vb + (size_t)key * DH + piece * 8);
-        }
-    };
-    auto store_stage = [&](int buf) {
-        unsigned char* Ks = lds[buf];
-        unsigned char* Vt = lds[buf] + EA_KSTAGE * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
-            st16(Ks + swz128(row, piece), rk[i]);
-            const unsigned w[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                      // transpose: V[key=row][d = 8*piece + 2k (+1)] -> Vt[d][key]
-                *reinterpret_cast<unsigned short*>(Vt + (piece * 8 + 2 * k) * EAB_VT_STRIDE + row * 2) = (unsigned short)(w[k] & 0xffffu);
-                *reinterpret_cast<unsigned short*>(Vt + (piece * 8 + 2 * k + 1) * EAB_VT_STRIDE + row * 2) = (unsigned short)(w[k] >> 16);
-            }
-        }
-    };
-
-    const int nstage = (N + EA_KSTAGE - 1) / EA_KSTAGE;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int s = 0; s < nstage; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nstage) load_stage(s + 1);
-        const unsigned char* Ks = lds[buf];
-        const unsigned char* Vt = lds[buf] + EA_KSTAGE * 128;
-
-        // ---- S^T for 64 keys x 32 queries: 16 MFMA ----
-        f32x4 sc[2][4];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            u32x4 kf[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kf[ks] = ld16(Ks + swz128(kt * 16 + lc, ks * 4 + lg));
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                mma16<bf16>(a, kf[0], qf[qt][0]);
-                mma16<bf16>(a, kf[1], qf[qt][1]);
-                sc[qt][kt] = a;
-            }
-        }
-        const int kbase = s * EA_KSTAGE;
-        if (kbase + EA_KSTAGE > N) {
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kbase + kt * 16 + lg * 4 + r >= N) { sc[0][kt][r] = -1e30f; sc[1][kt][r] = -1e30f; }
-        }
-        // ---- online softmax; P packed to bf16 k-step operands ----
-        u32x4 pb[2][2];                                        // [qt][32-key k-step]
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = sc[qt][0][0];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[qt][kt][r]);
-            mx = grp4_max(mx);
-            const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);
-            m_run[qt] = m_new;
-            float ps = 0.f;
-            unsigned pk[8];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                float p[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[qt][kt][r] - m_new); }
-                // packed hardware conversion (v_cvt_pk_bf16_f32, round to nearest even); the normaliser is summed in f32
-                pk[2 * kt] = pack_bf16x2(p[0], p[1]); pk[2 * kt + 1] = pack_bf16x2(p[2], p[3]);
-                ps += (p[0] + p[1]) + (p[2] + p[3]);
-            }
-            pb[qt][0] = u32x4{pk[0], pk[1], pk[2], pk[3]};     // key tiles 0,1 -> k-step 0
-            pb[qt][1] = u32x4{pk[4], pk[5], pk[6], pk[7]};     // key tiles 2,3 -> k-step 1
-            l_run[qt] = l_run[qt] * alpha + ps;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
-        }
-        // ---- O^T += V^T P^T : 16 MFMA ----
-#pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const unsigned char* vrow = Vt + (dt * 16 + lc) * EAB_VT_STRIDE + (k2 * 32 + lg * 4) * 2;
-                const uint2 lo = *reinterpret_cast<const uint2*>(vrow);          // keys 32k2 + 4g .. +3
-                const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 32);     // keys 32k2 + 16 + 4g .. +3
-                const u32x4 vf = {lo.x, lo.y, hi.x, hi.y};
-                mma16<bf16>(o[0][dt], vf, pb[0][k2]);
-                mma16<bf16>(o[1][dt], vf, pb[1][k2]);
-            }
-        }
-        if (s + 1 < nstage) store_stage(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- normalise, transpose through LDS (wave-private 32 x 64 f32 tile), store whole rows ----
-    float* tile = reinterpret_cast<float*>(&lds[0][0]) + wave * (32 * 64);
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        const float inv = 1.0f / grp4_sum(l_run[qt]);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                tile[(qt * 16 + lc) * 64 + ((dt * 16 + lg * 4 + r) ^ ((lc & 7) << 2))] = o[qt][dt][r] * inv;
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    const int inner = heads * DH;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int idx = it * 64 + lane, qq = idx >> 4, piece = idx & 15;
-        const int qrow = q0 + wave * 32 + qq;
-        if (qrow < N) {
-            const int c0 = (piece * 4) ^ ((qq & 7) << 2);
-            const float4 v4 = *reinterpret_cast<const float4*>(&tile[qq * 64 + c0]);
-            TO* dst = out + ((size_t)(b * N + qrow)) * inner + head * DH + piece * 4;
-            if constexpr (sizeof(TO) == 4) {
-                *reinterpret_cast<float4*>(dst) = v4;
-            } else {
-                union { bf16 h[4]; uint2 u; } t;
-                t.h[0] = __float2bfloat16(v4.x); t.h[1] = __float2bfloat16(v4.y);
-                t.h[2] = __float2bfloat16(v4.z); t.h[3] = __float2bfloat16(v4.w);
-                *reinterpret_cast<uint2*>(dst) = t.u;
-            }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // bf16 variant 2 (default in perf mode): the same tiling and the same S^T = K Q^T / O^T += V^T P^T orientation, with the

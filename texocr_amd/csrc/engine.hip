@@ -160,10 +160,10 @@ struct Engine : EngineBase {
     // TXO_PERSIST / TXO_LANES on a live engine).  Everything else in this struct's neighbourhood is read once, in the member initialisers.
     struct RunKnobs {
         int persist = -1, graph = -1, lanes = 0;        // -1 / 0 = unset
-        bool stamps = false, pstamps = false, lat_nofold = false;
+        bool stamps = false, pstamps = false;
         std::string stamps_file, pstamps_file;
-        int stagger_ticks = 0, poll_sleep = 1, early_mask = 0, poll_mode = 3, inject_fail = 0;
-        bool has_stagger = false, has_early = false, has_inject = false;
+        int stagger_ticks = 0, inject_fail = 0;
+        bool has_stagger = false, has_inject = false;
         void read() {
             *this = RunKnobs{};
             if (const char* e = getenv("TXO_PERSIST")) persist = atoi(e) != 0;
@@ -171,11 +171,7 @@ struct Engine : EngineBase {
             if (const char* e = getenv("TXO_LANES")) lanes = std::max(1, atoi(e));
             if (const char* e = getenv("TXO_STAMPS")) { stamps = true; stamps_file = e; }
             if (const char* e = getenv("TXO_PSTAMPS")) { pstamps = true; pstamps_file = e; }
-            lat_nofold = getenv("TXO_LAT_NOFOLD") != nullptr;
             if (const char* e = getenv("TXO_PS_STAGGER_US")) { has_stagger = true; stagger_ticks = (int)(atof(e) * 100.0); }
-            if (const char* e = getenv("TXO_PS_POLL_SLEEP")) poll_sleep = atoi(e);
-            if (const char* e = getenv("TXO_PS_EARLY")) { has_early = true; early_mask = atoi(e); }
-            if (const char* e = getenv("TXO_PS_POLL")) poll_mode = atoi(e);
             if (const char* e = getenv("TXO_PERSIST_INJECT_FAIL")) { has_inject = true; inject_fail = atoi(e); }
         }
     } knobs;
@@ -183,16 +179,14 @@ struct Engine : EngineBase {
     // experiment knobs are read ONCE per engine (never on a launch path)
     bool dec_wide_off = getenv("TXO_DEC_WIDE_OFF") != nullptr;
     // narrow decoder, folded latent out-projection (K = heads * D): 32 x 32 blocks from wide_min_rows rows of a range on, 32 x 16 blocks from
-    // wide_mid_rows on (TXO_WIDE_MID_ROWS=100000 switches them off), 16 x 16 blocks below
-    int wide_min_rows = getenv("TXO_WIDE_MIN_ROWS") ? atoi(getenv("TXO_WIDE_MIN_ROWS")) : 100000;   // (257 until the tiled operands: at a beam search's 320 rows per range 32 x 16 is now ahead, 98.5 vs 100.5 ms)
-    int wide_mid_rows = getenv("TXO_WIDE_MID_ROWS") ? atoi(getenv("TXO_WIDE_MID_ROWS")) : 129;
-    bool kw24_off = getenv("TXO_KW24_OFF") != nullptr;    // experiment switch: FFN-out at K = 3072 on the run-time-K tile (three request groups) instead of the fixed one
-    // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8): an experiment knob, TXO_ENC_NT=1.  probes/pp_store_policy.hip
+    // wide_mid_rows on, 16 x 16 blocks below
+    static constexpr int wide_min_rows = 100000;   // (257 until the tiled operands: at a beam search's 320 rows per range 32 x 16 is now ahead, 98.5 vs 100.5 ms)
+    static constexpr int wide_mid_rows = 129;
+    // encoder GEMM outputs with non-temporal stores (gemm_big.h: store8; the epilogues keep the parameter).  probes/pp_store_policy.hip
     // measured +22 % for a plain 256x256 store epilogue at K = 768 (1.85 GB of output per launch), but the encoder's own epilogues
     // (GeGLU halves the columns, the fp32 stream is read-modify-write) run the same with either policy: 45.84 vs 45.77 ms per ViT-Base
     // encode (probes/enc_nt.py) -- so the default stays the plain store.
-    int enc_nt_env = getenv("TXO_ENC_NT") ? atoi(getenv("TXO_ENC_NT")) : 0;
-    int enc_nt(size_t) const { return enc_nt_env; }
+    int enc_nt(size_t) const { return 0; }
     // cross attention in latent form (lat_attn.h): scores / values against the raw encoder rows instead of projected K/V panels.
     // latent_ok: the tile exists for this engine's width / storage type.  lat_mode (TXO_LATENT, read once): 1 = every decode runs with
     // launches in latent form, 0 = never, unset = where it measured faster (auto_latent).  use_latent: what the current session does.
@@ -207,22 +201,23 @@ struct Engine : EngineBase {
     bool lat_self = false;
     int lat_self_env = getenv("TXO_LATENT_SELF") ? atoi(getenv("TXO_LATENT_SELF")) : 0;
     bool lat_self_ok() const {
-        return lat_self_env != 0 && !dec_self.empty() && dec_self[0].wqp != nullptr && Tmax <= 16 * (D <= 256 ? 8 : 4) * LA_PATH_TILES;
+        // (the beam slot table of the tile covers 16 keys x its wave count x LA_PATH_TILES positions: the bf16 tile at width 256 runs on 4 waves)
+        const int waves = (D <= 256 && !(lat_nw4 && D == 256)) ? 8 : 4;
+        return lat_self_env != 0 && zc != nullptr && !dec_self.empty() && dec_self[0].wqp != nullptr && Tmax <= 16 * waves * LA_PATH_TILES;
     }
     int lat_mode = getenv("TXO_LATENT") ? atoi(getenv("TXO_LATENT")) : -1;
     int lat_g_env = getenv("TXO_LAT_G") ? atoi(getenv("TXO_LAT_G")) : 0;
-    // bf16, width 256: the latent tile on FOUR waves (r05; TXO_LAT_NW=8 brings the 8-wave tile back).  Same one tile per CU, half the waves to
+    // bf16, width 256: the latent tile on FOUR waves (r05).  Same one tile per CU, half the waves to
     // merge and twice the keys per wave: the whole-batch launch at 256 rows 19.3 -> 17.9 us (rocprofv3), generate +2-3 % at 130-192 rows,
     // beam search 5 x 128 +5 %.  (Two such tiles per CU, 512 tiles of 4 heads at 256 rows, were slower: 22.2 us -- every row's encoder
     // rows cross the CU's L2 port twice.)  The wave count changes the order in which a row's key tiles are merged: low bits differ from the
     // 8-wave tile's, within the same bound against the reference.
-    bool lat_nw4 = sizeof(T) == 2 && (getenv("TXO_LAT_NW") ? atoi(getenv("TXO_LAT_NW")) == 4 : true);
+    static constexpr bool lat_nw4 = sizeof(T) == 2;
     bool ckv_valid = false;           // the projected cross K/V panels of this session exist (the prefill needs them; the latent form does not)
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
-    int enc_walk = getenv("TXO_ENC_WALK") ? atoi(getenv("TXO_ENC_WALK")) : 1;   // encoder kernels walk the rows alternately up and down (encode()); 0 = all upwards
+    static constexpr int enc_walk = 1;   // encoder kernels walk the rows alternately up and down (encode())
     int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
     int pp_sb_mb = getenv("TXO_PP_SB_MB") ? atoi(getenv("TXO_PP_SB_MB")) : PP_SB_MB;   // ... its row super-blocks: MB of A per super-block, 0 = none (gemm_pp.h)
-    bool attn_v2 = getenv("TXO_ENC_ATTN_OLD") == nullptr;   // bf16: encoder attention with transposing LDS reads (enc_attn.h, variant 2)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
     // per-row stop (step.h): batch row held by every slot of a row range, scratch of the compaction, {live rows, moves} per range;
@@ -414,7 +409,8 @@ struct Engine : EngineBase {
             cat.insert(cat.end(), v->data.begin(), v->data.end());
             if (int r = upload_T(&w->wqkv, cat)) return r;
             // decoder self attention in latent form (r05): the same two folds, against the history of normalised block inputs
-            if (G == 8 && latent_fold()) { if (int r = fold_latent(q, k, v, wo, inner, w, G)) return r; }
+            // (opt-in, TXO_LATENT_SELF=1: without it neither the fold nor the z history exists)
+            if (G == 8 && latent_fold() && lat_self_env != 0) { if (int r = fold_latent(q, k, v, wo, inner, w, G)) return r; }
         }
         if (int r = upload_T(&w->wo, interleave(wo->data, D, inner, G))) return r;
         if (G != 16) {                                        // decoder: the prefill runs these projections on the encoder-side GEMMs
@@ -682,9 +678,11 @@ struct Engine : EngineBase {
         if (int r = dalloc(&dhid, (size_t)Bmax * Fmax)) return r;
         if (int r = dalloc(&dz, (size_t)Bmax * D)) return r;
         if (int r = dalloc(&dqt, (size_t)Bmax * Imax)) return r;
-        if (int r = dalloc(&zc, (size_t)c.dec_layers * Bmax * Tmax * D)) return r;
+        if (lat_self_env != 0) { if (int r = dalloc(&zc, (size_t)c.dec_layers * Bmax * Tmax * D)) return r; }   // z history of the opt-in latent self attention
         if (int r = dalloc(&dqp, (size_t)Bmax * c.dec_heads * D)) return r;
-        if (int r = dalloc(&dcl, ((size_t)Bmax + 16 * 4) * c.dec_heads * D)) return r;   // (+ tile alignment of the lanes' regions: c_base_row)
+        // (+ tile alignment of the row ranges' regions: range li starts at ceil16(b0) + 16 li and spans ceil16(nb) rows -- beam ranges are not
+        // multiples of 16 -- so the last of MAXL ranges can end at Bmax + 30 + 16 (MAXL - 1))
+        if (int r = dalloc(&dcl, ((size_t)Bmax + 16 * MAXL + 32) * c.dec_heads * D)) return r;
         if (int r = dalloc(&dlogits, (size_t)Bmax * V)) return r;
         if (int r = dalloc(&cur_tok, (size_t)Bmax)) return r;
         if (int r = dalloc(&eos_seen, (size_t)Bmax)) return r;
@@ -871,8 +869,7 @@ struct Engine : EngineBase {
                 bf16* qb = reinterpret_cast<bf16*>(eqkv);
                 gemm_plain(s, ez, enc_attn[l].wqkv, M, 3 * Ie, D,
                                    EpiHeads<bf16>{qb, hs, Ie, cfg.enc_heads, N, nt_qkv}, dir());
-                if (attn_v2) hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh, dir());
-                else hipLaunchKernelGGL((enc_attn_bf16_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh);
+                hipLaunchKernelGGL((enc_attn_bf16_v2_kernel<T>), agrid, dim3(256), 0, s, qb, qb + hs, qb + 2 * hs, eao, N, cfg.enc_heads, nbh, dir());
             }
             gemm_plain(s, eao, enc_attn[l].wo, M, 2 * D, Ie,
                                EpiGluRes<sizeof(T) == 2>{ey, l == 0 ? res_first : res_x, enc_attn[l].bo, nt_y}, dir());
@@ -1022,7 +1019,7 @@ struct Engine : EngineBase {
                     case 4: TXO_DG(4, 16); break;    case 6: TXO_DG(6, 16); break;    case 8: TXO_DG(8, 16); break;
                     case 12: TXO_DG(12, 16); break;  case 16: TXO_DG(16, 16); break;
                     case 24:                                 // K = 3072 (FFN-out of a 768-wide decoder): every fragment requested up front, one round trip instead of three
-                        if constexpr (EPI == EPI_BIAS_RES && sizeof(T) == 2) { if (!kw24_off) { TXO_DG(24, 16); break; } }
+                        if constexpr (EPI == EPI_BIAS_RES && sizeof(T) == 2) { TXO_DG(24, 16); break; }
                         TXO_DG(0, 16); break;
                     default: TXO_DG(0, 16);
                 }
@@ -1132,7 +1129,7 @@ struct Engine : EngineBase {
     // (row, head group) tile per CU the latent tile moves 493 KB per CU against 300 KB and is slower, 19 vs 16 us per launch at batch
     // 64); wide decoders (768: the in-tile projections' weights are 3.4 MB per row) and the fp32 parity mode keep the K/V form.
     // the latent form's two per-head projections fold into their neighbouring GEMMs (load_attn) where the folded weights stay small
-    bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D && !knobs.lat_nofold; }
+    bool latent_fold() const { return latent_ok && cfg.dec_heads * DH == 2 * D; }
     bool auto_latent(int rows) const { return sizeof(T) == 2 && D == 256 && rows > PERSIST_MAX_BF16_GREEDY; }
     // heads per latent tile: the smallest group that leaves at most one tile per CU for `rows` rows (fewer tiles = fewer
     // re-reads of an image's encoder rows; more tiles = more CUs pulling).  A head's bits do not depend on it.
@@ -1595,9 +1592,8 @@ struct Engine : EngineBase {
         const char* stamp_file = knobs.pstamps ? knobs.pstamps_file.c_str() : nullptr;
         pa.stamp_step = stamp_file ? std::min(max_len - 1, 200) : -1;
         if (knobs.has_stagger) pa.stagger_ticks = knobs.stagger_ticks;
-        pa.poll_sleep = knobs.poll_sleep;
-        if (knobs.has_early) pa.early_mask = knobs.early_mask;
-        pa.poll_mode = knobs.poll_mode;                           // default 3: scalar polls behind s_dcache_inv (persist.h: TeamSync::poll; -1.3 % per generate against vector polls)
+        pa.poll_sleep = 1;
+        pa.poll_mode = 3;                           // default 3: scalar polls behind s_dcache_inv (persist.h: TeamSync::poll; -1.3 % per generate against vector polls)
         if (knobs.has_inject) pa.inject_fail = knobs.inject_fail; // tests: the give-up / fall-back path
         HIP_TRY(hipMemsetAsync(pctl, 0, sizeof(PersistCtl), s));
         if (stamp_file) HIP_TRY(hipMemsetAsync(pstamps, 0, sizeof(unsigned long long) * PS_TEAMS * PS_STAMP_RANKS * PS_MAX_STAGES * PS_STAMP_WORDS, s));

@@ -414,8 +414,6 @@ inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M,
     const long long w_bytes = (long long)N * K * 2, coltile_bytes = (long long)PP_BN * K * 2;
     int ct = tiles_n;
     if (w_bytes > (5ll << 19) && K < 2048) ct = (int)std::max<long long>(1, std::min<long long>(tiles_n, (13ll << 17) / coltile_bytes));
-    static const int ct_env = [] { const char* e = getenv("TXO_PP_CT"); return e ? atoi(e) : 0; }();
-    if (ct_env > 0) ct = std::max(1, std::min(tiles_n, ct_env));
     // narrower last band: when tiles_n % ct != 0 the row-major walk of the last band uses its own width (tile_origin)
     // row super-block (kernel comment): only where there is more than one band; sb_mb = MB of A per super-block (0 = one super-block)
     int sbr = tiles_m;
