@@ -1787,7 +1787,7 @@ struct Engine : EngineBase {
         if (use_graph) for (int i = 0; i < n_lanes; ++i) if (int r = lane_graph(i, eos)) return r;
         if (n_lanes > 1) {
             HIP_TRY(hipEventRecord(ev_fork, s));
-            for (int i = 1; i < n_lanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
+            for (int i = 0; i < n_lanes; ++i) if (lanes[i].stream != s) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
         }
         int64_t* tdst = use_graph ? tok_buf : tokens_out;
         const int tstride = use_graph ? Tmax : max_len;               // rows of tokens_out are max_len apart (only n_pos positions are decoded here)
@@ -1862,7 +1862,8 @@ struct Engine : EngineBase {
         };
         if (int r = decode_loop()) return abandon_lanes(s, r);
         // join the lanes back into the caller's stream
-        for (int i = 1; i < n_lanes; ++i) {
+        for (int i = 0; i < n_lanes; ++i) {
+            if (lanes[i].stream == s) continue;
             HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
             HIP_TRY(hipStreamWaitEvent(s, ev_join[i], 0));
         }
