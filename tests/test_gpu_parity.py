@@ -990,11 +990,36 @@ def test_bf16_dma_gemm_bit_identical_to_register_staged(monkeypatch):
     from texocr_amd.config import reference_config
     dh = Dims.from_config(reference_config())
     imgh = torch.from_numpy(synth.synth_images(4, 1, 160, 1008, seed=92)).cuda()
-    h_old = build_with({"TXO_GEMM_OLD": "1"}, dh, seed=8, dtype="bf16", max_batch=4)
+    # (with the opt-in bf16 backbone: the default keeps the backbone and this projection in fp32, engine.hip: bk_fp32)
+    h_old = build_with({"TXO_GEMM_OLD": "1", "TXO_BACKBONE_BF16": "1"}, dh, seed=8, dtype="bf16", max_batch=4)
     ref_h = h_old.encoder(imgh)
     for env in forms:
-        h_new = build_with(env, dh, seed=8, dtype="bf16", max_batch=4)
+        h_new = build_with(dict(env, TXO_BACKBONE_BF16="1"), dh, seed=8, dtype="bf16", max_batch=4)
         assert torch.equal(h_new.encoder(imgh), ref_h), env
+
+
+def test_encoder_tile_walk_and_image_chunks_do_not_change_a_bit(monkeypatch):
+    """r06: (a) the 256x256 GEMM's persistent tile walk runs its column bands inside ROW SUPER-BLOCKS (gemm_pp.h: `sbr`; the A operand of a
+    super-block stays in the Infinity Cache across the bands) and (b) Engine::encode can push IMAGE CHUNKS through the stack one after the
+    other (TXO_ENC_CHUNK, an experiment knob).  Neither may change a bit: a tile's arithmetic does not depend on when it is computed, and rows
+    of different images never meet.  ViT-Base widths, 50 images = 116 row panels: super-blocks of 10 panels (eleven full, one of six), with
+    the walk direction alternating; chunks of 16 and of 7 images (ragged last chunk)."""
+    def build_with(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        try:
+            return build(d, seed=6, dtype="bf16", max_batch=50, max_tokens=589)[2]
+        finally:
+            for k in env:
+                monkeypatch.delenv(k)
+    d = Dims(canvas=672, embed_dim=768, enc_heads=12, enc_layers=2, dec_heads=12, dec_layers=1)
+    img = torch.from_numpy(synth.synth_images(50, 3, 224, 672, seed=95)).cuda()
+    ref = build_with({"TXO_PP_SB_MB": "0"}).encoder(img)                 # the r05 walk: every band over all row panels
+    assert bool(torch.isfinite(ref).all())
+    for env in ({}, {"TXO_PP_SB_MB": "4"}, {"TXO_PP_SB_MB": "4", "TXO_PP_CT": "2"}, {"TXO_ENC_CHUNK": "16"}, {"TXO_ENC_CHUNK": "7", "TXO_PP_SB_MB": "4"}):
+        m = build_with(env)
+        for _ in range(3):
+            assert torch.equal(m.encoder(img), ref), env
 
 
 def test_wide_decoder_large_batch_ffn_path():

@@ -217,6 +217,7 @@ struct Engine : EngineBase {
     bool use_pp = getenv("TXO_GEMM_OLD") == nullptr;   // bf16: 256x256 LDS-DMA GEMM for the encoder-side projections
     static constexpr int enc_walk = 1;   // encoder kernels walk the rows alternately up and down (encode())
     int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
+    int pp_ct = getenv("TXO_PP_CT") ? atoi(getenv("TXO_PP_CT")) : 0;     // experiment: column tiles per band of the multi-band GEMMs (0 = by size, gemm_pp.h)
     int pp_sb_mb = getenv("TXO_PP_SB_MB") ? atoi(getenv("TXO_PP_SB_MB")) : PP_SB_MB;   // ... its row super-blocks: MB of A per super-block, 0 = none (gemm_pp.h)
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
@@ -721,7 +722,7 @@ struct Engine : EngineBase {
     template <class Epi>
     void gemm_plain(hipStream_t s, const T* A, const T* W, int M, int N, int K, Epi epi, int rev = 0) {
         if constexpr (sizeof(T) == 2) {
-            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr, rev, pp_sb_mb); return; }
+            if (use_pp && gemm_pp_fits(M, N, K)) { launch_gemm_pp(s, A, W, M, N, K, epi, pp_tr, rev, pp_sb_mb, pp_ct); return; }
         }
         launch_gemm_big<T>(s, LoadPlain<T>{A, K}, W, M, N, K, epi);
     }

@@ -390,7 +390,7 @@ inline bool gemm_pp_fits(int M, int N, int K) {
 // The engine reads TXO_PP_TR once per engine and passes it here (tests build engines with each form and compare them bit for bit).
 
 template <class Epi, bool TR>
-inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int rev, int sb_mb) {
+inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int rev, int sb_mb, int ct_force) {
     const int tiles_m = (M + PP_BM - 1) / PP_BM, tiles_n = N / PP_BN;
     const int n_tiles = tiles_m * tiles_n;
     // persistent grid: one block per CU (128-160 KiB LDS each).  Both the CU count and the > 64 KiB dynamic-LDS opt-in are per
@@ -414,6 +414,7 @@ inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M,
     const long long w_bytes = (long long)N * K * 2, coltile_bytes = (long long)PP_BN * K * 2;
     int ct = tiles_n;
     if (w_bytes > (5ll << 19) && K < 2048) ct = (int)std::max<long long>(1, std::min<long long>(tiles_n, (13ll << 17) / coltile_bytes));
+    if (ct_force > 0 && ct < tiles_n) ct = std::max(1, std::min(tiles_n, ct_force));
     // narrower last band: when tiles_n % ct != 0 the row-major walk of the last band uses its own width (tile_origin)
     // row super-block (kernel comment): only where there is more than one band; sb_mb = MB of A per super-block (0 = one super-block)
     int sbr = tiles_m;
@@ -422,9 +423,9 @@ inline void launch_gemm_pp_t(hipStream_t s, const bf16* A, const bf16* W, int M,
     hipLaunchKernelGGL((gemm_pp_kernel<Epi, TR>), dim3(grid), dim3(PP_THREADS), smem, s, A, W, M, N, K, tiles_n, n_tiles, ct, sbr, rev, epi);
 }
 template <class Epi>
-inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1, int rev = 0, int sb_mb = PP_SB_MB) {
+inline void launch_gemm_pp(hipStream_t s, const bf16* A, const bf16* W, int M, int N, int K, Epi epi, int tr = -1, int rev = 0, int sb_mb = PP_SB_MB, int ct_force = 0) {
     if (tr < 0) tr = Epi::HAS_ROW ? 0 : 1;
-    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi, rev, sb_mb); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi, rev, sb_mb);
+    if (tr) launch_gemm_pp_t<Epi, true>(s, A, W, M, N, K, epi, rev, sb_mb, ct_force); else launch_gemm_pp_t<Epi, false>(s, A, W, M, N, K, epi, rev, sb_mb, ct_force);
 }
 
 }  // namespace txo
