@@ -352,6 +352,27 @@ def test_hybrid_oracle_wider_image_and_bf16():
     assert rel_emu < 0.5 * rel_q and abs(rel_q - emu_fp32) < 0.5 * emu_fp32
 
 
+def test_split_fp32_backbone_gemm_against_exact_f32():
+    """bf16 engine, hybrid embedder: the fp32 backbone's convolutions run as fp32 operands SPLIT onto the bf16 matrix pipe
+    (csrc/gemm_split.h: a = hi + lo, three bf16 MFMAs per product term, ~2^-16 per product).  Against the same engine with the exact-f32 MFMA
+    kernel (TXO_BACKBONE_EXACT=1) the 45-layer backbone + ViT output moves by far less than bf16 storage anywhere would (0.1-0.2), and
+    stays within the 2 % of the fp32 reference that the mode promises."""
+    from texocr_amd.config import reference_config
+    cpu_ref = _oracle()
+    d = Dims.from_config(reference_config())
+    img = torch.from_numpy(synth.synth_images(3, 1, 64, 320, seed=31))
+    _, sd, m_split = build(d, seed=9, dtype="bf16", max_batch=3, max_tokens=1 + 4 * 20)
+    _, _, m_exact = build(d, seed=9, dtype="bf16", max_batch=3, max_tokens=1 + 4 * 20, env={"TXO_BACKBONE_EXACT": "1"})
+    a, b = m_split.encoder(img.cuda()).cpu(), m_exact.encoder(img.cuda()).cpu()
+    ref = cpu_ref.encode(cpu_ref.to_torch_sd(sd), img, grid_w=d.grid)
+    scale = float(ref.abs().mean())
+    rel_ab = float((a - b).abs().mean()) / scale
+    rel_a, rel_b = float((a - ref).abs().mean()) / scale, float((b - ref).abs().mean()) / scale
+    print(f"hybrid encoder, bf16 engine: split backbone vs exact-f32 backbone {rel_ab:.5f}; vs fp32 oracle: split {rel_a:.5f}, exact {rel_b:.5f}")
+    assert rel_ab < 0.01 and rel_a < 0.02 and rel_b < 0.02
+    assert not torch.equal(a, b)                                      # (two different kernels did run)
+
+
 def test_hybrid_default_factory_full_canvas_golden():
     """N1 at its real size: create_model(config.yml) on the full 1x160x1008 canvas (631 tokens), two images, 32 greedy steps captured from
     the reference (tests/golden/hybrid_b2_160x1008, oracle/capture_golden.py: cap_hybrid_full).  fp32: tokens exact, logits < 1e-3;
@@ -371,14 +392,20 @@ def test_hybrid_default_factory_full_canvas_golden():
     encb = mb.encoder(img).cpu().numpy()
     rel = float(np.abs(encb - g["enc"]).mean() / np.abs(g["enc"]).mean())
     tb, lb = mb.generate(img, meta["max_len"], return_logits=True)
-    dl = float(np.abs(lb.cpu().numpy() - g["step_logits"]).max())
-    print(f"hybrid full canvas, bf16 engine vs reference: encoder mean-relative {rel:.4f}, max |dlogit| {dl:.4f}")
     assert rel < 0.02, rel
-    tb = tb.cpu().numpy()
-    for b in range(2):                                   # identical until the first step whose reference margin is inside the bf16 noise
-        small = np.nonzero(g["margin"][b] < 2.5 * dl)[0]
-        upto = int(small[0]) if small.size else tb.shape[1]
-        assert np.array_equal(tb[b, :upto], g["tokens"][b, :upto]), (b, upto)
+    tb, lb = tb.cpu().numpy(), lb.cpu().numpy()
+    # per row: logits are compared on the common prefix (behind a different token the two decodes see different inputs), and a token may
+    # differ only where the reference's own top-1 / top-2 margin is inside twice the deviation measured on that prefix
+    worst = 0.0
+    for b in range(2):
+        diff = np.nonzero(tb[b] != g["tokens"][b])[0]
+        k = int(diff[0]) if diff.size else tb.shape[1] - 1
+        dl = float(np.abs(lb[b, :k + 1] - g["step_logits"][b, :k + 1]).max())
+        worst = max(worst, dl)
+        if diff.size:
+            assert g["margin"][b, k] < 2 * dl, (b, k, float(g["margin"][b, k]), dl)
+    print(f"hybrid full canvas, bf16 engine vs reference: encoder mean-relative {rel:.4f}, max |dlogit| on the common prefixes {worst:.4f}")
+    assert worst < 0.06, worst                         # (twice the measured 0.030; the plain-ViT bf16 engine sits at 0.025)
 
 
 # ------------------------------------------------------------------------------------------------

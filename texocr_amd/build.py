@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libtexocr_hip.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["common.h", "prefill.h", "conv.h", "gemm_big.h", "gemm_pp.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "lat_attn.h", "step.h", "persist.h"]
+HEADERS = ["common.h", "prefill.h", "conv.h", "gemm_big.h", "gemm_pp.h", "gemm_split.h", "rows.h", "enc_attn.h", "dec_gemm.h", "dec_attn.h", "lat_attn.h", "step.h", "persist.h"]
 
 
 # Mandatory flags (never replaced by the environment):

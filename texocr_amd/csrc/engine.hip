@@ -23,6 +23,7 @@
 #include "enc_attn.h"
 #include "gemm_big.h"
 #include "gemm_pp.h"
+#include "gemm_split.h"
 #include "lat_attn.h"
 #include "persist.h"
 #include "prefill.h"
@@ -741,11 +742,22 @@ struct Engine : EngineBase {
         // LDS-DMA kernel where the shape fits it (the bottlenecks' expanding convolutions, 256 / 512 / 1024 output channels)
         if (k == 1 && stride == 1) {
             if constexpr (std::is_same<TB, T>::value) gemm_plain(s, in, w, B * H * W, OC, C, EpiStore<T>{out, OC, nullptr});
-            else launch_gemm_big<TB>(s, LoadPlain<TB>{in, C}, w, B * H * W, OC, C, EpiStore<TB>{out, OC, nullptr});
+            else bk_gemm(s, LoadPlain<TB>{in, C}, w, B * H * W, OC, C, EpiStore<TB>{out, OC, nullptr});
             return;
         }
         LoadConv<TB> ld{in, H, W, C, stride, pt, pl, FastDiv(OH * OW), FastDiv(OW), FastDiv(C), FastDiv(k)};
-        launch_gemm_big<TB>(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<TB>{out, OC, nullptr});
+        bk_gemm(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<TB>{out, OC, nullptr});
+    }
+    // a backbone GEMM in storage type TB.  fp32 backbone INSIDE the bf16 engine: fp32 operands split onto the bf16 matrix pipe
+    // (gemm_split.h: ~2^-16 per product, 5x less matrix time than exact-f32 MFMA); everything else -- the fp32 parity engine first of all --
+    // the exact kernel.  TXO_BACKBONE_EXACT=1 keeps the exact-f32 kernel in the bf16 engine too (A/B, tests).
+    bool bk_exact = getenv("TXO_BACKBONE_EXACT") != nullptr;
+    template <typename TB, class ALoad, class Epi>
+    void bk_gemm(hipStream_t s, ALoad ld, const TB* w, int M, int N, int K, Epi epi) {
+        if constexpr (sizeof(TB) == 4 && sizeof(T) == 2) {
+            if (!bk_exact && gemm_split_fits(K)) { launch_gemm_split(s, ld, w, M, N, K, epi); return; }
+        }
+        launch_gemm_big<TB>(s, ld, w, M, N, K, epi);
     }
     template <bool RELU, bool RES, typename TB>
     void group_norm(hipStream_t s, const TB* x, const TB* res, TB* y, const GnW& g, int B, int HW, int C) {
@@ -761,8 +773,7 @@ struct Engine : EngineBase {
         TB* const* act = k.act;
         int h1, w1, pt, pl;
         same_pad(H, 7, 2, &h1, &pt); same_pad(W, 7, 2, &w1, &pl);
-        launch_gemm_big<TB>(s, LoadStem<TB>{img, H, W, pt, pl, FastDiv(h1 * w1), FastDiv(w1)}, k.stem_w, B * h1 * w1, 64, 64,
-                            EpiStore<TB>{act[1], 64, nullptr});
+        bk_gemm(s, LoadStem<TB>{img, H, W, pt, pl, FastDiv(h1 * w1), FastDiv(w1)}, k.stem_w, B * h1 * w1, 64, 64, EpiStore<TB>{act[1], 64, nullptr});
         group_norm<true, false>(s, (const TB*)act[1], (const TB*)nullptr, act[1], k.stem_gn, B, h1 * w1, 64);
         int hc, wc, ppt, ppl;
         same_pad(h1, 3, 2, &hc, &ppt); same_pad(w1, 3, 2, &wc, &ppl);
@@ -836,7 +847,7 @@ struct Engine : EngineBase {
             if (bk_fp32) {
                 const float* feat = nullptr;
                 if (int r = backbone<float>(bk32, img, B, H, W, &feat, s)) return r;
-                launch_gemm_big<float>(s, LoadPlain<float>{feat, 1024}, bk32.proj_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
+                bk_gemm(s, LoadPlain<float>{feat, 1024}, (const float*)bk32.proj_w, B * hw, D, 1024, EpiTokens{ex, patch_b, pos, D, hw, w, G});
             } else {
                 const T* feat = nullptr;
                 if (int r = backbone<T>(bk, img, B, H, W, &feat, s)) return r;
