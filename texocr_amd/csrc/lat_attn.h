@@ -151,6 +151,10 @@ __device__ __forceinline__ void lat_core_tile(const LatCoreArgs<T>& a, int tile,
     // covers RPI consecutive rows completely (lane = row j * RPI + lane / CPR, piece lane % CPR); the tile goes to the wave's LDS image as before
     // and the score MFMAs take their fragments from the image.  Same values in the same MFMAs: the same bits.  The per-key slot tables of a beam
     // search's self attention (a.path) keep the fragment shape (a lane would need eight slots per tile).
+    // (r06, measured and NOT kept: the same shape for width 768 -- a tile's 16 consecutive rows requested as 24 linear KiB, three (row, piece)
+    // pairs per lane -- needs the fragments re-read from the image while both prefetch sets and 192 accumulator registers are live: the
+    // kernel spills inside the tile loop, 55 -> 123 us per launch; with buffer loads whose rows past the last key read as zero, width 256
+    // went 17.0 -> 18.2 us.  profiles/r06_cfg4_latent_form.txt)
     constexpr int CPR = ROWB / 16, RPI = CPR <= 64 ? 64 / CPR : 1;     // 16-byte pieces per row, rows per wave-instruction
     constexpr bool COAL_OK = FAST && CPR <= 64 && 64 % CPR == 0 && KC == 16 / RPI;
     const bool coal = COAL_OK && a.path == nullptr;
