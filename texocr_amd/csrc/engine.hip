@@ -656,7 +656,12 @@ struct Engine : EngineBase {
         if (hybrid) {
             // largest NHWC activation per image: stem output (H/2 x W/2 x 64) = stage-0 output (H/4 x W/4 x 256) = 4096 per token
             const size_t E = (size_t)Bmax * (Nmax - 1) * 4096;
-            if (bk_fp32) { for (auto& a : bk32.act) if (int r = dalloc(&a, E)) return r; }
+            if (bk_fp32) {
+                for (auto& a : bk32.act) if (int r = dalloc(&a, E)) return r;
+                // GroupNorm partial sums per 128-row output tile of the split convolutions: the stem's output is the largest (H/2 x W/2 pixels)
+                const size_t rows = (size_t)Bmax * ((c.canvas_h + 1) / 2) * ((c.canvas_w + 1) / 2);
+                if (int r = dalloc(&gn_tiles, (rows / GB_BM + 2) * 2 * 2 * 32 * 2)) return r;
+            }
             else { for (auto& a : bk.act) if (int r = dalloc(&a, E)) return r; }
             if (int r = dalloc(&gn_partial, (size_t)Bmax * 64 * 64)) return r;
             if (int r = dalloc(&gn_stats, (size_t)Bmax * 64)) return r;
@@ -742,28 +747,43 @@ struct Engine : EngineBase {
         // LDS-DMA kernel where the shape fits it (the bottlenecks' expanding convolutions, 256 / 512 / 1024 output channels)
         if (k == 1 && stride == 1) {
             if constexpr (std::is_same<TB, T>::value) gemm_plain(s, in, w, B * H * W, OC, C, EpiStore<T>{out, OC, nullptr});
-            else bk_gemm(s, LoadPlain<TB>{in, C}, w, B * H * W, OC, C, EpiStore<TB>{out, OC, nullptr});
+            else bk_gemm(s, LoadPlain<TB>{in, C}, w, B * H * W, OC, C, EpiStore<TB>{out, OC, nullptr}, H * W);
             return;
         }
         LoadConv<TB> ld{in, H, W, C, stride, pt, pl, FastDiv(OH * OW), FastDiv(OW), FastDiv(C), FastDiv(k)};
-        bk_gemm(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<TB>{out, OC, nullptr});
+        bk_gemm(s, ld, w, B * OH * OW, OC, k * k * C, EpiStore<TB>{out, OC, nullptr}, OH * OW);
     }
     // a backbone GEMM in storage type TB.  fp32 backbone INSIDE the bf16 engine: fp32 operands split onto the bf16 matrix pipe
     // (gemm_split.h: ~2^-16 per product, 5x less matrix time than exact-f32 MFMA); everything else -- the fp32 parity engine first of all --
     // the exact kernel.  TXO_BACKBONE_EXACT=1 keeps the exact-f32 kernel in the bf16 engine too (A/B, tests).
     bool bk_exact = getenv("TXO_BACKBONE_EXACT") != nullptr;
+    // gn_hw > 0: the output is the input of a GroupNorm over images of gn_hw pixels -- the split kernel then leaves the norm's partial sums
+    // behind (gemm_split.h: GnPart) and group_norm() skips its own pass over the tensor (gn_fused)
+    bool gn_fused = false;
+    float* gn_tiles = nullptr;        // [row tiles][2 halves][2 images][32 groups][2]
     template <typename TB, class ALoad, class Epi>
-    void bk_gemm(hipStream_t s, ALoad ld, const TB* w, int M, int N, int K, Epi epi) {
+    void bk_gemm(hipStream_t s, ALoad ld, const TB* w, int M, int N, int K, Epi epi, int gn_hw = 0) {
+        gn_fused = false;
         if constexpr (sizeof(TB) == 4 && sizeof(T) == 2) {
-            if (!bk_exact && gemm_split_fits(K)) { launch_gemm_split(s, ld, w, M, N, K, epi); return; }
+            if (!bk_exact && gemm_split_fits(K)) {
+                GnPart gp{nullptr, 1, 1};
+                if (gn_hw > 0 && gn_tiles && gn_fusable(gn_hw, N)) { gp = GnPart{gn_tiles, gn_hw, N / 32}; gn_fused = true; }
+                launch_gemm_split(s, ld, w, M, N, K, epi, gp);
+                return;
+            }
         }
         launch_gemm_big<TB>(s, ld, w, M, N, K, epi);
     }
     template <bool RELU, bool RES, typename TB>
     void group_norm(hipStream_t s, const TB* x, const TB* res, TB* y, const GnW& g, int B, int HW, int C) {
-        const int chunk_px = std::max(256, (HW + 63) / 64), nchunk = (HW + chunk_px - 1) / chunk_px;
-        hipLaunchKernelGGL((gn_partial_kernel<TB>), dim3(nchunk, B), dim3(256), 0, s, x, gn_partial, HW, C, chunk_px);
-        hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(32), 0, s, gn_partial, gn_stats, nchunk, (double)HW * (C / 32));
+        if (gn_fused) {                                      // the convolution that wrote x left the partial sums per output tile (bk_gemm)
+            gn_fused = false;
+            hipLaunchKernelGGL(gn_finish_tiles_kernel, dim3(B), dim3(32), 0, s, gn_tiles, gn_stats, HW, (double)HW * (C / 32));
+        } else {
+            const int chunk_px = std::max(256, (HW + 63) / 64), nchunk = (HW + chunk_px - 1) / chunk_px;
+            hipLaunchKernelGGL((gn_partial_kernel<TB>), dim3(nchunk, B), dim3(256), 0, s, x, gn_partial, HW, C, chunk_px);
+            hipLaunchKernelGGL(gn_finish_kernel, dim3(B), dim3(32), 0, s, gn_partial, gn_stats, nchunk, (double)HW * (C / 32));
+        }
         const size_t nvec = (size_t)B * HW * C / Elem<TB>::PER16;
         hipLaunchKernelGGL((gn_apply_kernel<TB, RELU, RES>), dim3((nvec + 255) / 256), dim3(256), 0, s, x, res, y, gn_stats, g.g,
                            g.b, HW, C, nvec);
@@ -773,7 +793,7 @@ struct Engine : EngineBase {
         TB* const* act = k.act;
         int h1, w1, pt, pl;
         same_pad(H, 7, 2, &h1, &pt); same_pad(W, 7, 2, &w1, &pl);
-        bk_gemm(s, LoadStem<TB>{img, H, W, pt, pl, FastDiv(h1 * w1), FastDiv(w1)}, k.stem_w, B * h1 * w1, 64, 64, EpiStore<TB>{act[1], 64, nullptr});
+        bk_gemm(s, LoadStem<TB>{img, H, W, pt, pl, FastDiv(h1 * w1), FastDiv(w1)}, k.stem_w, B * h1 * w1, 64, 64, EpiStore<TB>{act[1], 64, nullptr}, h1 * w1);
         group_norm<true, false>(s, (const TB*)act[1], (const TB*)nullptr, act[1], k.stem_gn, B, h1 * w1, 64);
         int hc, wc, ppt, ppl;
         same_pad(h1, 3, 2, &hc, &ppt); same_pad(w1, 3, 2, &wc, &ppl);

@@ -32,9 +32,17 @@ __device__ inline void split4(const u32x4& x, uint2& hi, uint2& lo) {
     lo.x = pk(x0 - h0, x1 - h1); lo.y = pk(x2 - h2, x3 - h3);
 }
 
+// GroupNorm statistics from the epilogue (conv.h: every convolution of the backbone is followed by GroupNorm(32) over its output): while the
+// output tile sits in LDS, the sum and the sum of squares of every (image, group) it covers are written to a slot of `part`
+//     part[((tile_m * 2 + row half) * 2 + which) * 32 + group] = {sum, sum of squares}      which = 0: the image of the tile's first row, 1: the next
+// (rows = pixels, a tile of 128 rows covers at most two images when HW >= 128).  Every slot is written by exactly one thread and
+// gn_finish_tiles_kernel adds them in a fixed order: deterministic, no float atomics -- and the separate pass over the convolution's output
+// (gn_partial_kernel: 2.4 of the backbone's 12.6 ms) is gone.  part == nullptr: off.
+struct GnPart { float* part; int HW, cpg; };
+
 template <class ALoad, class Epi>
 __global__ __launch_bounds__(GB_THREADS) void gemm_split_kernel(ALoad aload, const float* __restrict__ W, int M, int N, int K, int tiles_n,
-                                                                int n_tiles, Epi epi) {
+                                                                int n_tiles, Epi epi, GnPart gn) {
     constexpr int STAGE_K = 32;                                       // fp32 elements per row and stage = one 16x16x32 MFMA k-step
     __shared__ __attribute__((aligned(16))) unsigned char lds[2][4][GB_BM * 64];   // [buf][A_hi | A_lo | W_hi | W_lo][row * 64 B]
 
@@ -122,6 +130,28 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_split_kernel(ALoad aload, con
             for (int r = 0; r < 4; ++r) tile[tidx(wm + 16 * i + lg * 4 + r, wn + 16 * j + lr)] = acc[i][j][r];
     __syncthreads();
     static_assert(!Epi::PAIRED, "the backbone's epilogues are plain stores");
+    if (gn.part) {
+        // thread = (column c of the tile, row half rh): 64 rows of one output channel, split at the image boundary
+        const int c = tid & 127, rh = tid >> 7;
+        const int mlim = min(GB_BM, M - m0);                           // rows of the tile that exist
+        const int split = min(mlim, (m0 / gn.HW + 1) * gn.HW - m0);    // rows [0, split): the first image; [split, mlim): the next
+        float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+        for (int r = rh * 64; r < rh * 64 + 64; ++r) {
+            const float v = tile[tidx(r, c)];
+            const bool in0 = r < split, in1 = r >= split && r < mlim;
+            s0 += in0 ? v : 0.f; q0 = in0 ? fmaf(v, v, q0) : q0;
+            s1 += in1 ? v : 0.f; q1 = in1 ? fmaf(v, v, q1) : q1;
+        }
+        // the cpg channels of a group are cpg adjacent lanes (cpg = 2 .. 32, a power of two)
+        for (int o = 1; o < gn.cpg; o <<= 1) {
+            s0 += __shfl_xor(s0, o, 64); q0 += __shfl_xor(q0, o, 64); s1 += __shfl_xor(s1, o, 64); q1 += __shfl_xor(q1, o, 64);
+        }
+        const int n = n0 + c;
+        if ((c & (gn.cpg - 1)) == 0 && n < N) {
+            float* dst = gn.part + ((((size_t)tile_m * 2 + rh) * 2) * 32 + n / gn.cpg) * 2;
+            dst[0] = s0; dst[1] = q0; dst[64] = s1; dst[65] = q1;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int idx = tid + GB_THREADS * q, row = idx >> 4, cg = idx & 15;
@@ -136,11 +166,31 @@ __global__ __launch_bounds__(GB_THREADS) void gemm_split_kernel(ALoad aload, con
 
 inline bool gemm_split_fits(int K) { return K % 32 == 0; }
 
+// per (image, group): mean and 1 / sqrt(var + eps) from the tile slots above, added in tile order (fp64 combine, as conv.h: gn_finish_kernel)
+__global__ void gn_finish_tiles_kernel(const float* __restrict__ part, float* __restrict__ stats, int HW, double count) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    if (g >= 32) return;
+    const int t0 = (int)(((long long)b * HW) / GB_BM), t1 = (int)((((long long)b + 1) * HW - 1) / GB_BM);
+    double a = 0.0, d = 0.0;
+    for (int t = t0; t <= t1; ++t) {
+        const int which = ((long long)t * GB_BM) / HW == b ? 0 : 1;
+        for (int rh = 0; rh < 2; ++rh) {
+            const float* p = part + ((((size_t)t * 2 + rh) * 2 + which) * 32 + g) * 2;
+            a += p[0]; d += p[1];
+        }
+    }
+    const double mean = a / count;
+    const double var = fmax(d / count - mean * mean, 0.0);
+    stats[((size_t)b * 32 + g) * 2 + 0] = (float)mean;
+    stats[((size_t)b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
+}
+inline bool gn_fusable(int HW, int C) { const int cpg = C / 32; return HW >= GB_BM && C % 32 == 0 && cpg >= 1 && cpg <= 32 && (cpg & (cpg - 1)) == 0; }
+
 template <class ALoad, class Epi>
-inline void launch_gemm_split(hipStream_t s, ALoad aload, const float* W, int M, int N, int K, Epi epi) {
+inline void launch_gemm_split(hipStream_t s, ALoad aload, const float* W, int M, int N, int K, Epi epi, GnPart gn = GnPart{nullptr, 1, 1}) {
     const int tiles_m = (M + GB_BM - 1) / GB_BM, tiles_n = (N + GB_BN - 1) / GB_BN;
     const int n_tiles = tiles_m * tiles_n;
-    hipLaunchKernelGGL((gemm_split_kernel<ALoad, Epi>), dim3(n_tiles), dim3(GB_THREADS), 0, s, aload, W, M, N, K, tiles_n, n_tiles, epi);
+    hipLaunchKernelGGL((gemm_split_kernel<ALoad, Epi>), dim3(n_tiles), dim3(GB_THREADS), 0, s, aload, W, M, N, K, tiles_n, n_tiles, epi, gn);
 }
 
 }  // namespace txo
