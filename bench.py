@@ -466,8 +466,9 @@ def side_measurement(dims, dtype, B, a, dev, warm, steps, want_cross, want_encod
                                                 "latent_form = B*N*D*s",
                            "kv_form_equivalent_GBps": round(algo_kv / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0,
                            "avg_launch_us": round(ms * 1e3, 2), "launches_timed": n}
-        try:        # PMC bytes of the same whole-batch launch from the separate rocprofv3 passes of probes/profile_r05.sh (not measured in this run)
-            fn = os.path.join("profiles", f"r05_pmc_{dtype}_b{B}" + ("" if latent or dims.embed_dim != 256 else "_kvform") + ".json")
+        try:        # PMC bytes of the same whole-batch launch from the separate rocprofv3 passes of probes/profile_r0N.sh (not measured in this run)
+            fn = next(f for f in (os.path.join("profiles", f"{rnd}_pmc_{dtype}_b{B}" + ("" if latent or dims.embed_dim != 256 else "_kvform") + ".json")
+                                  for rnd in ("r06", "r05")) if os.path.exists(os.path.join(ROOT, f)))
             pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]
             if pm["config"] == {"batch": B, "dtype": dtype, "tokens": N} and pm.get("rows_per_launch") == B and ("lat_core" in pm["kernel"]) == latent and dims.embed_dim == 256:
                 out["roofline"]["traffic"] = pm["traffic_bytes"]
@@ -592,7 +593,7 @@ def main():
             algo_cross = a.batch * heads * 2 * N * 64 * esz                 # one cross-attention launch / stage: K and V panels once
             mfma_peak = 2500.0 if a.dtype == "bf16" else 157.3              # dense TFLOP/s, MI355X_MICROARCH.md
             def pmc(kind):
-                for rnd in ("r05", "r04", "r03", "r02", "r01"):
+                for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
                     fn = os.path.join("profiles", f"{rnd}_pmc_{kind}{a.dtype}_b{a.batch}.json")
                     try:
                         pm = json.load(open(os.path.join(ROOT, fn)))["traffic"]
@@ -644,7 +645,7 @@ def main():
             finally:
                 os.environ.pop("TXO_PERSIST")
             traffic, tsrc = None, None
-            for rnd in ("r05", "r04", "r03", "r02", "r01"):
+            for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
                 fn = os.path.join("profiles", f"{rnd}_pmc_{a.dtype}_b{a.batch}.json")
                 try:
                     pm = json.load(open(os.path.join(ROOT, fn)))["cross_attention_traffic"]

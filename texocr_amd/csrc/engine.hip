@@ -6,9 +6,11 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -151,8 +153,11 @@ struct Engine : EngineBase {
         int b0 = 0, nb = 0;
         hipStream_t stream = nullptr;      // lane 0 runs on the caller's stream
         hipStream_t own = nullptr;         // engine-owned stream for lanes > 0
-        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-        int gb0 = -1, gnb = -1, gN = -1, geos = -2, gsB = -1, gsImg = -1, glat = -1;   // what the captured graph was built for (the cache strides sB / sImg are baked into its launches)
+        // captured steps, by what they were built for: {b0, nb, N, eos, sB, sImg, form flags} (the cache strides sB / sImg and the row count are
+        // baked into a graph's launches).  Per-row stop replays a step per row count of the shrinking range (multiples of 16): a handful of
+        // entries per range, built once and kept across generates.  exec = the entry the current decode replays.
+        std::map<std::array<int, 7>, std::pair<hipGraph_t, hipGraphExec_t>> graphs;
+        hipGraphExec_t exec = nullptr;
     };
     Lane lanes[MAXL];
     int n_lanes = 1, max_lanes = 2;
@@ -220,12 +225,20 @@ struct Engine : EngineBase {
     int pp_tr = getenv("TXO_PP_TR") ? (atoi(getenv("TXO_PP_TR")) != 0) : -1;   // its epilogue form: 1 direct, 0 staged through LDS, unset = by epilogue (gemm_pp.h)
     int pp_ct = getenv("TXO_PP_CT") ? atoi(getenv("TXO_PP_CT")) : 0;     // experiment: column tiles per band of the multi-band GEMMs (0 = by size, gemm_pp.h)
     int pp_sb_mb = getenv("TXO_PP_SB_MB") ? atoi(getenv("TXO_PP_SB_MB")) : PP_SB_MB;   // ... its row super-blocks: MB of A per super-block, 0 = none (gemm_pp.h)
+    // Two row ranges need two streams whose launches really run side by side.  Which HIP streams do depends on how the runtime mapped them onto
+    // hardware queues -- on every stream the process created before (profiles/r06_b256_stream_pairs.txt: 66 / 72 / 80 / 110 ms per generate
+    // at batch 256 for the same engine, by the number of streams created earlier) -- so the pair is CHOSEN by measurement, once per engine,
+    // the first time two ranges are wanted: tune_lane_streams().  TXO_TUNE_LANES=0: off (range 0 on the caller's stream, as r02-r05).
+    int tune_lanes = getenv("TXO_TUNE_LANES") ? atoi(getenv("TXO_TUNE_LANES")) : 1;
+    bool lanes_tuned = false;
+    double tune_best_ms = 0, tune_worst_ms = 0;
     int* flags_host = nullptr;        // pinned: done flags of the chunk being looked at (generate)
     hipEvent_t ev_flags[MAXL] = {};
     // per-row stop (step.h): batch row held by every slot of a row range, scratch of the compaction, {live rows, moves} per range;
     // live_host (pinned): the ranges' finished-row counts on their way to the host, ev_live behind them
     int *row_map = nullptr, *row_map2 = nullptr, *cmoves = nullptr, *cinfo = nullptr; int64_t* cur_tok2 = nullptr;
     int* live_host = nullptr; hipEvent_t ev_live[MAXL] = {};
+    bool stop_graph_on = getenv("TXO_STOP_GRAPH") ? atoi(getenv("TXO_STOP_GRAPH")) != 0 : true;
     int stop_every = getenv("TXO_STOP_EVERY") ? std::max(1, atoi(getenv("TXO_STOP_EVERY"))) : 16;   // positions between two looks at the live-row counts
     int stop_gain = getenv("TXO_STOP_GAIN") ? std::max(1, atoi(getenv("TXO_STOP_GAIN"))) : 16;      // rows a compaction must free (one 16-row tile)
     int last_compactions = 0;         // compactions of the last generate (TXO_Q_LAST_COMPACTIONS)
@@ -265,8 +278,7 @@ struct Engine : EngineBase {
 
     ~Engine() override {
         for (auto& ln : lanes) {
-            if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
-            if (ln.graph) (void)hipGraphDestroy(ln.graph);
+            for (auto& g : ln.graphs) { if (g.second.second) (void)hipGraphExecDestroy(g.second.second); if (g.second.first) (void)hipGraphDestroy(g.second.first); }
             if (ln.own) (void)hipStreamDestroy(ln.own);
         }
         if (cap_stream) (void)hipStreamDestroy(cap_stream);
@@ -954,7 +966,8 @@ struct Engine : EngineBase {
     // engine's buffers.  The caller's stream is made to wait for every lane, drained, and the engine goes back to one lane; the error
     // code passes through.
     int abandon_lanes(hipStream_t s, int rc) {
-        for (int i = 1; i < n_lanes; ++i) {
+        for (int i = 0; i < n_lanes; ++i) {
+            if (lanes[i].stream == s) continue;
             if (hipEventRecord(ev_join[i], lanes[i].stream) == hipSuccess) (void)hipStreamWaitEvent(s, ev_join[i], 0);
             else (void)hipStreamSynchronize(lanes[i].stream);
         }
@@ -963,6 +976,54 @@ struct Engine : EngineBase {
         set_lanes(1, s);
         stamp_slot = -1;
         return rc;
+    }
+    // Pick the two streams of a two-range decode: NCAND candidate streams, every pair timed on two chains of 160 launches that hold one wave
+    // per CU for 4 us each; the best pair becomes lanes[0].own / lanes[1].own, the rest is destroyed.  ~60 ms, once per engine.
+    int tune_lane_streams() {
+        lanes_tuned = true;
+        constexpr int NCAND = 6, CHAIN = 160;
+        hipStream_t cand[NCAND] = {};
+        for (auto& c : cand) HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        // two chains of SHORT launches (a decode position is ~30 dependent launches of 3-15 us per range) behind a 2 ms gate that lets the host
+        // enqueue both chains before either starts; timed by events on the streams: the later end of the two
+        hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
+        auto run_pair = [&](hipStream_t a, hipStream_t b) -> double {
+            double best = 1e30;
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+                hipLaunchKernelGGL(hold_kernel, dim3(1), dim3(64), 0, a, 200000);          // the gate
+                (void)hipEventRecord(e0, a);
+                (void)hipStreamWaitEvent(b, e0, 0);
+                for (int i = 0; i < CHAIN; ++i) {
+                    hipLaunchKernelGGL(hold_kernel, dim3(n_cus), dim3(64), 0, a, 400);
+                    hipLaunchKernelGGL(hold_kernel, dim3(n_cus), dim3(64), 0, b, 400);
+                }
+                (void)hipEventRecord(ea, a); (void)hipEventRecord(eb, b);
+                (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+                float ta = 0, tb = 0;
+                (void)hipEventElapsedTime(&ta, e0, ea); (void)hipEventElapsedTime(&tb, e0, eb);
+                best = std::min(best, (double)std::max(ta, tb));
+            }
+            return best;
+        };
+        (void)run_pair(cand[0], cand[1]);                                  // (code object load, clocks)
+        int bi = 0, bj = 1; double bt = 1e30, wt = 0;
+        for (int i = 0; i < NCAND; ++i)
+            for (int j = i + 1; j < NCAND; ++j) {
+                const double t = run_pair(cand[i], cand[j]);
+                if (t < bt) { bt = t; bi = i; bj = j; }
+                wt = std::max(wt, t);
+            }
+        tune_best_ms = bt; tune_worst_ms = wt;
+        if (lanes[0].own) (void)hipStreamDestroy(lanes[0].own);
+        if (lanes[1].own) (void)hipStreamDestroy(lanes[1].own);
+        lanes[0].own = cand[bi]; lanes[1].own = cand[bj];
+        for (int i = 0; i < NCAND; ++i) if (i != bi && i != bj) (void)hipStreamDestroy(cand[i]);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+        if (getenv("TXO_TUNE_LANES_VERBOSE")) fprintf(stderr, "[txo] row-range streams: pair (%d, %d) of %d candidates, %.2f ms (worst pair %.2f ms)\n", bi, bj, NCAND, bt, wt);
+        HIP_TRY(hipGetLastError());
+        return 0;
     }
     // split the batch into n contiguous row ranges (multiples of 16 rows where possible)
     void set_lanes(int n, hipStream_t s) {
@@ -978,6 +1039,7 @@ struct Engine : EngineBase {
             row += lanes[i].nb;
             lanes[i].stream = i == 0 ? s : lanes[i].own;
         }
+        if (n >= 2 && lanes[0].own) lanes[0].stream = lanes[0].own;
     }
     void reset_lanes(hipStream_t s, int eos) {
         for (int i = 0; i < n_lanes; ++i) {
@@ -1421,17 +1483,23 @@ struct Engine : EngineBase {
     // capture lane li's step (tokens into the engine-owned tok_buf) as a graph, or reuse the cached one
     int lane_graph(int li, int eos) {
         Lane& ln = lanes[li];
-        if (ln.exec && ln.gb0 == ln.b0 && ln.gnb == ln.nb && ln.gN == sN && ln.geos == eos && ln.gsB == sB && ln.gsImg == sImg && ln.glat == (int)use_latent + 2 * (int)lat_self) return 0;
-        if (ln.exec) { (void)hipGraphExecDestroy(ln.exec); ln.exec = nullptr; }
-        if (ln.graph) { (void)hipGraphDestroy(ln.graph); ln.graph = nullptr; }
+        const std::array<int, 7> key = {ln.b0, ln.nb, sN, eos, sB, sImg, (int)use_latent + 2 * (int)lat_self + 4 * (int)row_stop + 8 * sample_mode};
+        auto it = ln.graphs.find(key);
+        if (it != ln.graphs.end()) { ln.exec = it->second.second; return 0; }
+        if (ln.graphs.size() >= 64) {                              // (shapes keep changing: start over rather than grow without bound)
+            for (auto& g : ln.graphs) { (void)hipGraphExecDestroy(g.second.second); (void)hipGraphDestroy(g.second.first); }
+            ln.graphs.clear();
+        }
         hipStream_t cs = cap_stream;
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
         HIP_TRY(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
         const int r = enqueue_step(cs, li, tok_buf, Tmax, nullptr, eos);
-        hipError_t e = hipStreamEndCapture(cs, &ln.graph);
+        hipError_t e = hipStreamEndCapture(cs, &graph);
         if (r) return r;
         if (e != hipSuccess) return fail(TXO_E_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
-        HIP_TRY(hipGraphInstantiate(&ln.exec, ln.graph, nullptr, nullptr, 0));
-        ln.gb0 = ln.b0; ln.gnb = ln.nb; ln.gN = sN; ln.geos = eos; ln.gsB = sB; ln.gsImg = sImg; ln.glat = (int)use_latent + 2 * (int)lat_self;
+        HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        ln.graphs[key] = {graph, exec};
+        ln.exec = exec;
         return 0;
     }
 
@@ -1800,7 +1868,11 @@ struct Engine : EngineBase {
         lat_self = use_latent && lat_self_ok() && !row_stop;      // (the z history is not moved by compact_lane)
         if (!use_latent) ensure_ckv(s);
         const bool want_graph = knobs.graph >= 0 ? knobs.graph != 0 : B <= 4;
-        const bool eager = logits_out != nullptr || g_dbg || sample_mode || !want_graph || row_stop;   // (a captured step has its row count baked in)
+        // per-row stop replays captured steps: as the ranges shrink a position's launches take less time than the host needs to enqueue them
+        // (68 launches for two ranges: ~230 us per position on the host against 130 us on the device at 40 % of the rows), and a step
+        // per row count (multiples of 16) is captured once and kept (lane_graph).  TXO_STOP_GRAPH=0: eager launches.
+        const bool stop_graph = row_stop && !sample_mode && stop_graph_on;
+        const bool eager = logits_out != nullptr || g_dbg || sample_mode || !(want_graph || stop_graph);
         // two row ranges on two streams for a WIDE decoder at >= 256 rows (BASELINE cfg 4): one range's latency-bound projection launches
         // run beside the other's HBM-bound attention launches (816 -> 834 images/s; four ranges: 765).  Greedy and sampled alike: a draw is keyed
         // by (seed; row of the batch, position), not by the range (step.h: StepArgs::row0)
@@ -1812,6 +1884,7 @@ struct Engine : EngineBase {
         if (want == 2 && use_latent && D < 512 && B < 224) want = 1;
         if (knobs.lanes > 0) want = std::min(knobs.lanes, max_lanes);
         if (B < 32) want = 1;
+        if (want == 2 && tune_lanes && !lanes_tuned) { if (int r = tune_lane_streams()) return r; }
         set_lanes(want, s);
         last_ranges = n_lanes;
         reset_lanes(s, eos);
@@ -1865,8 +1938,12 @@ struct Engine : EngineBase {
                 if (live_pend >= 0 && t == live_pend + AHEAD) {
                     for (int i = 0; i < n_lanes; ++i) HIP_TRY(hipEventSynchronize(ev_live[i]));
                     for (int i = 0; i < n_lanes; ++i) {
-                        const int bound = lanes[i].nb - live_host[i];
-                        if (bound >= 1 && lanes[i].nb - bound >= stop_gain) { if (int r2 = compact_lane(i, bound, t + 1, eos)) return r2; }
+                        int bound = lanes[i].nb - live_host[i];
+                        if (use_graph) bound = std::min(lanes[i].nb, (bound + 15) & ~15);      // a captured step per multiple of 16 rows
+                        if (bound >= 1 && lanes[i].nb - bound >= stop_gain) {
+                            if (int r2 = compact_lane(i, bound, t + 1, eos)) return r2;
+                            if (use_graph) { if (int r2 = lane_graph(i, eos)) return r2; }
+                        }
                     }
                     live_pend = -1;
                 }
@@ -1965,6 +2042,7 @@ struct Engine : EngineBase {
         // an image's k beams together; self-attention slots are range-local); every range has its own step state and done flags.
         int want = (rows >= 256 && B >= 2 && !prof && !prof_cross && !g_dbg) ? 2 : 1;
         if (knobs.lanes > 0) want = std::max(1, std::min(std::min(knobs.lanes, max_lanes), B));
+        if (want == 2 && tune_lanes && !lanes_tuned) { if (int r = tune_lane_streams()) { sB = B; return r; } }
         if (want > 1) {
             n_lanes = want;
             int img0 = 0;
@@ -1973,6 +2051,7 @@ struct Engine : EngineBase {
                 lanes[i].b0 = img0 * beams; lanes[i].nb = ni * beams; lanes[i].stream = i == 0 ? s : lanes[i].own;
                 img0 += ni;
             }
+            if (lanes[0].own) lanes[0].stream = lanes[0].own;          // (the measured pair: tune_lane_streams)
         }
         last_ranges = n_lanes;
         const int n = std::max(rows, Tmax);
@@ -1983,7 +2062,7 @@ struct Engine : EngineBase {
                                done_flag + (size_t)i * Tmax, 0, beams, Tmax, cfg.bos);
         if (n_lanes > 1) {
             HIP_TRY(hipEventRecord(ev_fork, s));
-            for (int i = 1; i < n_lanes; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
+            for (int i = 0; i < n_lanes; ++i) if (lanes[i].stream != s) HIP_TRY(hipStreamWaitEvent(lanes[i].stream, ev_fork, 0));
         }
         // same non-draining eos look as generate(): once every beam is finished further steps only repeat eos at no cost
         // (beam_select_kernel), so the few steps enqueued ahead of the look change neither scores nor slots.  A range's flag stays
@@ -2032,7 +2111,8 @@ struct Engine : EngineBase {
         return 0;
         };
         if (int r = beam_loop()) { sB = B; return abandon_lanes(s, r); }
-        for (int i = 1; i < n_lanes; ++i) {                           // join the ranges back into the caller's stream
+        for (int i = 0; i < n_lanes; ++i) {                           // join the ranges back into the caller's stream
+            if (lanes[i].stream == s) continue;
             HIP_TRY(hipEventRecord(ev_join[i], lanes[i].stream));
             HIP_TRY(hipStreamWaitEvent(s, ev_join[i], 0));
         }

@@ -651,6 +651,12 @@ __global__ void reset_state_kernel(StepState* st, int64_t* cur_tok, int* eos_see
 
 __global__ void set_position_kernel(StepState* st, int t) { st->t = t; st->arrive = 0u; }
 
+// holds one wave per workgroup for `ticks` x 10 ns (Engine::tune_lane_streams: do two streams' launches overlap?)
+__global__ void hold_kernel(int ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(4);
+}
+
 template <typename T>
 __global__ void cast_rows_kernel(const float* __restrict__ in, T* __restrict__ out, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
