@@ -314,9 +314,9 @@ def backbone_flop(B, H, W):
 
 def hybrid_measurement(dtype, a, dev, B=64):
     """The model create_model(config/config.yml) actually builds: hybrid ResNetV2 [2,4,6] embedder on the full
-    1 x 160 x 1008 canvas (631 tokens), config.yml dims behind it; greedy, max_len as the headline.  encoder_ms = backbone + ViT stack
-    (marker events); backbone_ms = the same encode minus the ViT stack's kernels is not separable by events, so the backbone is timed by
-    encoding with the stack's share measured on the plain-patch model of the same token count (reported as vit_stack_ms)."""
+    1 x 160 x 1008 canvas (631 tokens), config.yml dims behind it; greedy, max_len as the headline.  encoder_ms = backbone + ViT stack (wall time
+    of back-to-back encodes); the backbone's share is that minus the ViT stack alone, measured on the plain-patch model at the same token count
+    (vit_stack_ms)."""
     import torch
     from texocr_amd import synth
     from texocr_amd.config import Dims, reference_config
@@ -350,7 +350,9 @@ def hybrid_measurement(dtype, a, dev, B=64):
     torch.cuda.empty_cache()
     b_ms = max(e_ms - v_ms, 1e-3)
     fl = backbone_flop(B, H, W)
-    # the bf16 engine keeps this backbone in fp32 (engine.hip: bk_fp32): its roofline is the exact-f32 MFMA peak in both modes
+    # the bf16 engine keeps this backbone in fp32 STORAGE with fp32-accurate products: fp32 operands split hi + lo onto the bf16 matrix pipe
+    # (csrc/gemm_split.h: three bf16 MFMAs per product term); the fp32 engine uses exact-f32 MFMA.  `achieved` counts the convolution's own
+    # FLOPs once (fp32-equivalent); `peak` is the exact-f32 MFMA peak, the yardstick of an fp32 GEMM -- the split kernel may exceed it
     peak = 157.3
     tf = fl / (b_ms * 1e-3) / 1e12
     return {"value": round(B / sec, 2), "unit": "images/sec", "ms_per_step": round(1000 * sec, 3), "batch": B, "dtype": dtype,
@@ -358,8 +360,9 @@ def hybrid_measurement(dtype, a, dev, B=64):
             "decode_path": "one persistent launch" if persistent else "one launch per stage",
             "encoder_ms": round(e_ms, 3), "vit_stack_ms": round(v_ms, 3), "backbone_ms": round(b_ms, 3),
             "backbone_mfma": {"achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                              "flop": fl, "arithmetic": "fp32 storage and exact-f32 MFMA in both engine modes (bf16 storage moves these 45 random-weight "
-                                                        "layers by 10-20 %: tests/test_oracle_golden.py)"}}
+                              "flop": fl, "arithmetic": ("fp32 storage; products as fp32 operands split onto the bf16 matrix pipe (~2^-16 per product)" if dtype == "bf16"
+                                                        else "fp32 storage, exact-f32 MFMA") +
+                                                       " -- bf16 storage moves these 45 random-weight layers by 10-20 % (tests/test_oracle_golden.py)"}}
 
 
 def row_stop_measurement(dims, dtype, a, dev, B=256, target_median=90):
