@@ -516,7 +516,20 @@ def main():
     dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run (also with one rank)
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries exactly ONE JSON line (the bench
+        # contract), so the banner goes to stderr: file descriptor 1 points at 2 until the communicator exists
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            warm = torch.zeros(8, device=dev)
+            dist.all_reduce(warm)                       # the communicator (and its banner) now
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     dims = Dims(canvas=max(a.height, a.width))          # config.yml dims, PatchEmbedding front end, C=3
     if a.model == "cfg4":
