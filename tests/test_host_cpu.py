@@ -96,6 +96,13 @@ def _worker(rank, world, port, total, q):
         assert torch.equal(tk, out) and lg.shape == (out.shape[0], out.shape[1], 3) and torch.equal(lg[..., 0].long(), out)
         rows = all_gather_rows(torch.full((hi - lo, 2), rank), [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]
                                                                for r in range(world)])
+        # per-row stop on the gathered batch: the global break's step count, pad behind every row's first eos
+        out_row = sharded_generate(_fake_generate, imgs, 10, eos=5, bos=12, stop="row", pad=99)
+        assert out_row.shape == out.shape
+        for b in range(out.shape[0]):
+            hit = (out[b] == 5).nonzero()
+            n = int(hit[0]) + 1 if hit.numel() else out.shape[1]
+            assert torch.equal(out_row[b, :n], out[b, :n]) and bool((out_row[b, n:] == 99).all())
         q.put((rank, out.numpy(), out2.numpy(), rows.numpy()))
     finally:
         dist.destroy_process_group()

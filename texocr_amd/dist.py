@@ -40,6 +40,18 @@ def global_eos_steps(tokens: torch.Tensor, eos: Optional[int], bos: Optional[int
     return int(idx[0].item()) + 1 if idx.numel() else T
 
 
+def pad_after_eos(tokens: torch.Tensor, eos: Optional[int], pad: int, bos: Optional[int] = None) -> torch.Tensor:
+    """stop='row' (build extension, see texocr.h: txo_set_stop_mode) on a gathered batch: every token behind a row's first eos becomes `pad`
+    (a row whose BOS already is eos is finished from the start, decoder.py:115 looks at the whole output)."""
+    if eos is None or tokens.numel() == 0:
+        return tokens
+    is_eos = (tokens == eos).to(torch.int32)
+    prior = (torch.cumsum(is_eos, dim=1) - is_eos) > 0
+    if bos is not None and bos == eos:
+        prior = torch.ones_like(prior)
+    return torch.where(prior, torch.full_like(tokens, pad), tokens)
+
+
 def all_gather_rows(local: torch.Tensor, counts: List[int], group=None, force: bool = False) -> torch.Tensor:
     """All-gather row blocks of possibly different heights (pads to the tallest, one collective).  force: issue the
     collective even in a one-rank group (bench.py under torchrun --nproc-per-node 1 times the RCCL call itself)."""
@@ -61,7 +73,7 @@ def all_gather_rows(local: torch.Tensor, counts: List[int], group=None, force: b
 def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor], images: torch.Tensor, max_len: int,
                      eos: Optional[int], bos: Optional[int] = None, group=None,
                      images_are_local: bool = False, global_batch: Optional[int] = None, gather_logits: bool = False,
-                     force_collective: bool = False):
+                     force_collective: bool = False, stop: str = "global", pad: Optional[int] = None):
     """Data-parallel generate.
 
     generate_local(img_shard, max_len) -> (b_local, max_len) int64 tokens decoded WITHOUT the eos break
@@ -70,13 +82,21 @@ def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor]
     images_are_local=True, already this rank's shard (then `global_batch` gives the total row count).
     Returns the GLOBAL (B, n_steps) token tensor on every rank.  With gather_logits=True, generate_local returns
     (tokens, logits (b_local, max_len, V)) and the per-step logits are all-gathered as well (one more collective,
-    B/G * T * V * 4 bytes per rank -- 65 MB at 64 x 256 x 1000), returning (tokens, logits)."""
+    B/G * T * V * 4 bytes per rank -- 65 MB at 64 x 256 x 1000), returning (tokens, logits).
+    stop='row' (needs `pad`): the per-row stop's rewrite -- pad behind every row's first eos -- applied to the gathered, trimmed batch; the
+    number of steps is the global break's (what one device returns for the whole batch with stop='row')."""
+    if stop not in ("global", "row") or (stop == "row" and pad is None):
+        raise ValueError("stop must be 'global' or 'row' (with the pad id)")
+
     def unpack(r):
         return r if gather_logits else (r, None)
+
+    def finish(t):
+        return pad_after_eos(t, eos, pad, bos) if stop == "row" else t
     if not dist.is_initialized():
         toks, lg = unpack(generate_local(images, max_len))
         n = global_eos_steps(toks, eos, bos)
-        return (toks[:, :n], lg[:, :n]) if gather_logits else toks[:, :n]
+        return (finish(toks[:, :n]), lg[:, :n]) if gather_logits else finish(toks[:, :n])
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     if images_are_local:
         total = global_batch if global_batch is not None else images.shape[0] * world
@@ -96,8 +116,8 @@ def sharded_generate(generate_local: Callable[[torch.Tensor, int], torch.Tensor]
     full = all_gather_rows(toks, counts, group, force=force_collective)
     n = global_eos_steps(full, eos, bos)
     if gather_logits:
-        return full[:, :n], all_gather_rows(lg, counts, group, force=force_collective)[:, :n]
-    return full[:, :n]
+        return finish(full[:, :n]), all_gather_rows(lg, counts, group, force=force_collective)[:, :n]
+    return finish(full[:, :n])
 
 
 def generate_bucketed(generate_fn: Callable[[torch.Tensor], torch.Tensor], images, max_batch: int = 64):
