@@ -197,6 +197,20 @@ def test_row_stop_bf16_batch_256_compacts_and_keeps_every_row():
     assert np.array_equal(row.numpy(), want)
 
 
+def test_row_stop_with_return_logits_pads_and_does_not_compact():
+    d, sd, img = _stop_case()
+    ref = _oracle()
+    want = ref.generate_cached(ref.to_torch_sd(sd), img, d.bos, d.eos, d.max_len, stop="row", pad=d.pad).numpy()
+    _, _, m = build(d, sd=sd, max_batch=40, env=STOP_ENV)
+    t, lg = m.generate(img.cuda(), d.max_len, stop="row", return_logits=True)
+    assert m._engine.query(Q_LAST_COMPACTIONS) == 0 and lg.shape == (40, d.max_len, d.vocab)
+    assert np.array_equal(t.cpu().numpy(), want)
+    enc = m.encoder(img.cuda())
+    start = torch.full((40, 1), d.bos, dtype=torch.long, device="cuda")
+    t2, lg2 = m.decoder.generate(start, d.eos, d.max_len, enc=enc, stop="row", pad=d.pad, return_logits=True)
+    assert np.array_equal(t2.cpu().numpy(), want) and torch.equal(lg2, lg)
+
+
 def test_stop_mode_argument_checks():
     meta, g = load_golden("eos_break")
     d, sd, m = build(meta)

@@ -418,10 +418,15 @@ class AutoRegressiveDecoder(nn.Module):
                 eng.set_sampling(False)
             if stop == "row":
                 eng.set_stop_mode("global")
-        if stop == "row" and eos_tok is not None and not return_logits:
-            # (the engine's own generate has padded already; the stepwise loop -- arbitrary start prefix, padding mask -- is padded here:
-            # the same rule, tokens behind a row's first eos, start tokens included in the test as decoder.py:115 does)
-            out = _pad_after_eos(out, st.to(out.device), eos_tok, eng.dims.pad if pad is None else int(pad))
+        if stop == "row" and eos_tok is not None:
+            # (the engine's own generate has padded already; the stepwise loop -- arbitrary start prefix, padding mask -- and the
+            # return_logits form are padded here: the same rule, tokens behind a row's first eos, start tokens included in the test as
+            # decoder.py:115 does.  Logits behind a row's eos are what the finished row kept producing: unspecified.)
+            p_id = eng.dims.pad if pad is None else int(pad)
+            if return_logits:
+                out = (_pad_after_eos(out[0], st.to(out[0].device), eos_tok, p_id), out[1])
+            else:
+                out = _pad_after_eos(out, st.to(out.device), eos_tok, p_id)
         if return_logits:
             return (out[0].squeeze(0), out[1].squeeze(0)) if squeeze else out
         return out.squeeze(0) if squeeze else out
@@ -547,10 +552,11 @@ class OCRModel(nn.Module):
             return self._engine.generate_beam(src, beam, max_len, self.eos_token, return_beams=return_beams)
         if decode == "greedy" and self.bos_token == self._engine.dims.bos:
             # (max_len > decoder.max_len: txo_generate slides the window like the reference, decoder.py:99-100)
-            if stop == "row" and not return_logits:
+            if stop == "row":
+                # (with return_logits the engine does not compact -- a finished row's logits would be missing -- and only pads)
                 self._engine.set_stop_mode("row")
                 try:
-                    return self._engine.generate(src, max_len, self.eos_token)
+                    return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
                 finally:
                     self._engine.set_stop_mode("global")
             return self._engine.generate(src, max_len, self.eos_token, return_logits=return_logits)
