@@ -72,6 +72,25 @@ int main(int argc, char** argv) {
         for (int t = 0; t < want_steps; ++t)
             if (got[(size_t)b * max_len + t] != want[(size_t)b * want_steps + t]) { bad = 1; fprintf(stderr, "row %d step %d: got %lld, reference %lld\n", b, t, (long long)got[(size_t)b * max_len + t], (long long)want[(size_t)b * want_steps + t]); break; }
     printf("%s: %d images, %d steps (reference %d): tokens %s\n", txo_version(), B, n_steps, want_steps, bad ? "DIFFER" : "match the reference");
+    /* per-row stop (build extension, texocr.h: txo_set_stop_mode): the same call returns the same steps, every row equal to the reference up to
+     * its first eos and cfg.pad behind it */
+    if (!bad && cfg.eos >= 0) {
+        int32_t n2 = 0;
+        if (txo_set_stop_mode(e, TXO_STOP_ROW)) die("txo_set_stop_mode");
+        if (txo_generate(e, d_img, B, dims[1], dims[2], dims[3], max_len, cfg.eos, d_tok, &n2, NULL, NULL)) die("txo_generate (row stop)");
+        if (txo_set_stop_mode(e, TXO_STOP_GLOBAL)) die("txo_set_stop_mode");
+        if (hipMemcpy(got, d_tok, (size_t)B * max_len * 8, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy back");
+        bad = n2 != want_steps;
+        for (int b = 0; b < B && !bad; ++b) {
+            int done = cfg.bos == cfg.eos;
+            for (int t = 0; t < want_steps && !bad; ++t) {
+                const int64_t w = done ? cfg.pad : want[(size_t)b * want_steps + t];
+                if (got[(size_t)b * max_len + t] != w) bad = 1;
+                if (want[(size_t)b * want_steps + t] == cfg.eos) done = 1;
+            }
+        }
+        printf("per-row stop: %d steps, tokens %s\n", n2, bad ? "DIFFER" : "match the reference up to each row's eos, pad behind it");
+    }
     txo_engine_destroy(e);
     hipFree(d_img); hipFree(d_tok);
     free(img); free(want); free(got);

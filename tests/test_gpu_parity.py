@@ -1554,7 +1554,8 @@ def test_torch_free_c_program_on_the_c_abi(tmp_path):
     subprocess.run([sys.executable, os.path.join(root, "examples", "make_tiny_blob.py"), blob], check=True, capture_output=True)
     r = subprocess.run([exe, blob], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "match the reference" in r.stdout
+    assert "tokens match the reference" in r.stdout
+    assert "per-row stop" in r.stdout and "match the reference up to each row's eos" in r.stdout     # txo_set_stop_mode from plain C
 
 
 # ------------------------------------------------------------------------------------------------
