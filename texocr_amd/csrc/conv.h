@@ -64,7 +64,7 @@ template <typename T> struct LoadStem {
 struct EpiTokens {
     float* x; const float* bias; const float* pos; int D, hw, w, Gw;
     static constexpr bool PAIRED = false;
-    static constexpr int ST = 2;                    // 16-byte store instructions per fin() (gemm_pp.h)
+    static constexpr int ST = store8_insts<float>();   // 16-byte store instructions per fin() (gemm_pp.h)
     static constexpr int NCB = 8;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int b = m / hw, p = m - b * hw, pr = p / w, pc = p - pr * w;

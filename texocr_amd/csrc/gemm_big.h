@@ -52,6 +52,9 @@ template <typename T> struct LoadPatch {
 // nt: non-temporal stores.  The outputs of the encoder-side GEMMs are far larger than the caches and are next read by ANOTHER kernel; written
 // with the default policy they are allocated in L2 and push the GEMM's own operand panels out of it (probes/pp_store_policy.hip, 150 784 rows,
 // K = 768: 903-915 TFLOP/s with plain stores, 1094-1141 with non-temporal ones; K = 3072: no difference).  Wave-uniform flag.
+// 16-byte store instructions ONE store8<TO>() issues: the epilogue functors derive their ST from it (gemm_pp.h counts a tile's stores in its
+// relaxed seam wait, vmcnt(4 + stores): ST may understate -- the wait is then stricter than needed -- but must NEVER overstate)
+template <typename TO> constexpr int store8_insts() { return sizeof(TO) == 4 ? 2 : 1; }
 template <typename TO> __device__ inline void store8(TO* p, const float (&v)[8], int nt = 0) {
     if constexpr (sizeof(TO) == 4) {
         const f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
@@ -72,7 +75,7 @@ __device__ inline void load8(const float* p, float (&v)[8]) {
 template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
     T* out; int ldo; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
-    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;   // 16-byte store instructions per fin() (gemm_pp.h counts a tile's stores)
+    static constexpr int ST = store8_insts<T>();        // 16-byte store instructions per fin() (gemm_pp.h counts a tile's stores)
     static constexpr int NCB = 8;                       // entries of cb[] that cols() fills
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         if (bias) { float b[8]; load8(bias + n, b);
@@ -98,7 +101,7 @@ template <typename T> struct EpiStore {           // out[m][n..] = acc (+ bias)
 template <typename T> struct EpiHeads {           // scatter n = (which, head, d) into which-th [B,heads,Ntok,64]
     T* base; size_t which_stride; int inner, heads, ntok; int nt = 0;
     static constexpr bool PAIRED = false;
-    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;
+    static constexpr int ST = store8_insts<T>();
     static constexpr int NCB = 0;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
@@ -139,7 +142,7 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
     float* y; ResidLN res; const float* bias;     // bias is in the interleaved order
     int nt = 0;
     static constexpr bool PAIRED = true;
-    static constexpr int ST = 2;
+    static constexpr int ST = store8_insts<float>();    // one store8<float> per fin()
     static constexpr int NCB = 32;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8], r[10], cg[16];
@@ -164,7 +167,7 @@ struct EpiGluRes {                                // y[m][j..] = (v+bv) * sigmoi
 template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g+bg)
     T* h; const float* bias; int F; int nt = 0;
     static constexpr bool PAIRED = true;
-    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;
+    static constexpr int ST = store8_insts<T>();
     static constexpr int NCB = 16;
     __device__ inline void operator()(int m, int j, int nv, int ng, float (&v)[8], const float (&g)[8]) const {
         float bv[8], bg[8];
@@ -187,7 +190,7 @@ template <typename T> struct EpiGeglu {           // h[m][j..] = (v+bv) * gelu(g
 struct EpiBiasRes {                               // y[m][n..] = acc + bias + resid
     float* y; ResidLN res; const float* bias; int nt = 0;
     static constexpr bool PAIRED = false;
-    static constexpr int ST = 2;
+    static constexpr int ST = store8_insts<float>();    // one store8<float> per fin()
     static constexpr int NCB = 24;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         float b[8], r[10], cg[16];

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restri
 template <typename T> struct EpiHeadsKV {
     T* q; T* kc; T* vc; int inner, heads, t, tmax;
     static constexpr bool PAIRED = false;
-    static constexpr int ST = sizeof(T) == 4 ? 2 : 1;   // 16-byte store instructions per fin() (gemm_pp.h)
+    static constexpr int ST = store8_insts<T>();        // 16-byte store instructions per fin() (gemm_pp.h)
     static constexpr int NCB = 0;
     __device__ inline void operator()(int m, int n, float (&v)[8]) const {
         const int which = n / inner, f = n - which * inner, head = f >> 6, d = f & 63;   // 8 columns never straddle a head
