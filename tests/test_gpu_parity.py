@@ -1956,4 +1956,16 @@ def test_latent_self_attention_history(dtype):
         assert np.array_equal(toks[[11, 2]].cpu().numpy(), g["tokens"])
         v = torch.gather(logits[[11, 2]].cpu(), 2, torch.from_numpy(g["top5_ids"].astype(np.int64)))
         assert float((v - torch.from_numpy(g["top5_vals"])).abs().max()) < 1e-3
+    else:
+        # bf16 beam search in this form: the width-256 bf16 tile runs on FOUR waves, so its beam slot table covers 16 x 4 x 4 = 256
+        # positions.  Inside that range the z history must reproduce the K/V history's beams (within bf16 noise: the same best first tokens);
+        # a positional table beyond it (max_length 300) makes the engine decline the form and take the K/V history -- bit for bit the engine
+        # built without the knob -- instead of reading another beam's history.
+        bk = m_kv.generate(img[:3].cuda(), 24, beam=4).cpu()
+        bz = m_z.generate(img[:3].cuda(), 24, beam=4).cpu()
+        assert bz.shape == bk.shape and int((bz == bk).int().cumprod(1).sum(1).min()) >= 4
+        d300 = Dims(canvas=224, max_len=300)
+        _, sd3, a = build(d300, seed=14, dtype="bf16", max_batch=30, latent=1)
+        _, _, b = build(d300, seed=14, dtype="bf16", max_batch=30, latent=1, env=env)
+        assert torch.equal(a.generate(img[:3].cuda(), 280, beam=4), b.generate(img[:3].cuda(), 280, beam=4))
 
