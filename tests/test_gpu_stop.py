@@ -197,6 +197,30 @@ def test_row_stop_bf16_batch_256_compacts_and_keeps_every_row():
     assert np.array_equal(row.numpy(), want)
 
 
+@pytest.mark.parametrize("bias,breaks", [(1.4, True), (1.0, False)])
+def test_row_stop_beyond_the_positional_table(bias, breaks):
+    """max_len > decoder.max_len: the reference slides its window (decoder.py:99-100); rows whose first eos falls inside the window region
+    (positions 8..) are padded behind it like any other, and the loop ends where the reference's does.  Against the oracle's RECOMPUTE mode
+    (the reference algorithm as written) with stop='row'; persistent-launch and launch-path engines alike take the window's multi-position pass."""
+    ref = _oracle()
+    d = Dims(canvas=64, in_channels=3, embed_dim=64, enc_heads=2, enc_layers=2, dec_heads=2, dec_layers=2, vocab=64, max_len=8, bos=62, eos=61, pad=63)
+    sd = synth.synth_state_dict(d, 7)
+    b = sd["decoder.net.to_logits.bias"].copy()
+    b[d.eos] += bias
+    sd["decoder.net.to_logits.bias"] = b
+    img = torch.from_numpy(synth.synth_images(6, 3, 32, 48, seed=11)) * torch.linspace(0.2, 3.0, 6)[:, None, None, None]
+    want = ref.generate_recompute(ref.to_torch_sd(sd), img, d.bos, d.eos, 24, stop="row", pad=d.pad).numpy()
+    first = _first_eos(want, d.eos)
+    assert (want.shape[1] < 24) == breaks and max(first) >= d.max_len            # at least one row finishes beyond the table
+    _, _, m = build(d, sd=sd, max_batch=6, env=STOP_ENV)
+    t = m.generate(img.cuda(), 24, stop="row")
+    assert m._engine.query(Q_LAST_COMPACTIONS) == 0                              # (no compaction when the window may be needed)
+    assert np.array_equal(t.cpu().numpy(), want)
+    glob = m.generate(img.cuda(), 24).cpu()
+    full = torch.cat([torch.full((6, 1), d.bos, dtype=torch.long), glob], 1)
+    assert np.array_equal(ref.pad_after_eos(full, 1, d.eos, d.pad).numpy(), want)
+
+
 def test_row_stop_with_return_logits_pads_and_does_not_compact():
     d, sd, img = _stop_case()
     ref = _oracle()
