@@ -1280,7 +1280,25 @@ def test_persistent_decode_under_real_cu_contention(held_cus, hold_ms):
         tl, ll = m.generate(img, 48, return_logits=True)
     finally:
         os.environ.pop("TXO_PERSIST")
-    side = torch.cuda.Stream()
+    # the filler must run BESIDE the decode: two HIP streams that the runtime mapped onto one hardware queue run one after the other
+    # (profiles/r06_b256_stream_pairs.txt) -- the filler would then simply finish first and nothing would be contended.  Take a side stream
+    # that demonstrably runs side by side with the current one (a 3 ms one-CU hold on it must not delay a trivial launch here).
+    side, tried = None, []
+    for _ in range(12):
+        cand = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        assert hooks.txo_test_hold_cus(1, 1024, 3000, C.c_void_p(cand.cuda_stream)) == 0
+        t0 = time.perf_counter()
+        _ = torch.zeros(16, device="cuda") + 1
+        torch.cuda.current_stream().synchronize()
+        beside = time.perf_counter() - t0 < 1.5e-3
+        cand.synchronize()
+        tried.append(cand)                                      # (kept alive: the pool then hands out another stream)
+        if beside:
+            side = cand
+            break
+    if side is None:
+        pytest.skip("no side stream runs beside the current stream in this process")
     before = m._engine.query(1)
     os.environ["TXO_PERSIST"] = "1"
     try:
